@@ -1,0 +1,1012 @@
+// pt_device.hpp -- device-side rendering math of the gfx950 path tracer.
+//
+// Written for CDNA4: one lane = one path, all per-path state in VGPRs, scene constants in SGPRs /
+// the scalar cache, no shared mutable sampler state.  The arithmetic follows the reference's
+// megakernel path (file:line citations relative to /root/reference/examples/triangles/;
+// CC/ = cuda-core/) so that images agree with it to within float rounding:
+//   * host-branch semantics wherever the reference has host/device branches (software fp16
+//     round-half-up, table lookup with (size-1) scaling) -- see DESIGN.md "Numerics";
+//   * documented quirks of the reference are kept (see each function).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dmt_ggx_tables.inc"
+
+#define DMT_DEV __device__ __forceinline__
+
+namespace dmt {
+
+// ---------------------------------------------------------------------------------------------
+// vectors
+// ---------------------------------------------------------------------------------------------
+struct f2 {
+  float x, y;
+};
+struct f3 {
+  float x, y, z;
+};
+DMT_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+DMT_DEV f2 mk2(float x, float y) { return f2{x, y}; }
+DMT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DMT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DMT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+DMT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+DMT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+DMT_DEV f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+DMT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+DMT_DEV f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+DMT_DEV f3 operator+(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
+DMT_DEV f3 operator+(float s, f3 a) { return mk3(a.x + s, a.y + s, a.z + s); }
+DMT_DEV f3 operator-(f3 a, float s) { return mk3(a.x - s, a.y - s, a.z - s); }
+DMT_DEV f3 operator-(float s, f3 a) { return mk3(s - a.x, s - a.y, s - a.z); }
+DMT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DMT_DEV float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
+DMT_DEV f3 cross(f3 a, f3 b) {
+  return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+DMT_DEV float rsqrt_ieee(float x) { return 1.0f / sqrtf(x); }  // host rsqrtf of the reference
+DMT_DEV f3 normalize(f3 a) {                                   // CC common_math.cuh:297-300
+  float const inv = rsqrt_ieee(a.x * a.x + a.y * a.y + a.z * a.z);
+  return mk3(a.x * inv, a.y * inv, a.z * inv);
+}
+DMT_DEV f3 abs3(f3 a) { return mk3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+DMT_DEV f3 sqrt3(f3 a) { return mk3(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)); }
+DMT_DEV float sqr(float x) { return x * x; }
+DMT_DEV float safe_sqrt(float x) { return sqrtf(fmaxf(x, 0.f)); }
+DMT_DEV float max3(f3 v) { return fmaxf(v.x, fmaxf(v.y, v.z)); }
+DMT_DEV bool is_zero(f3 v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f; }
+DMT_DEV bool near_zero_pos(f3 v, float tol) { return v.x < tol && v.y < tol && v.z < tol; }
+DMT_DEV float luminance(f3 c) { return 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z; }
+DMT_DEV float average(f3 a) { return (a.x + a.y + a.z) / 3.f; }
+DMT_DEV float lerp1(float a, float b, float t) {
+  float const omt = 1.f - t;
+  return omt * a + t * b;
+}
+DMT_DEV f3 lerp3(f3 a, f3 b, float t) {
+  float const omt = 1.f - t;
+  return omt * a + t * b;
+}
+DMT_DEV float safe_acos(float v) { return acosf(fminf(fmaxf(v, -1.f), 1.f)); }
+DMT_DEV float sin_from_cos(float c) { return safe_sqrt(1.f - sqr(c)); }
+DMT_DEV float sin_sqr_to_one_minus_cos(float s) {  // common_math.cuh:439-443
+  return s > 0.0004f ? 1.0f - safe_sqrt(1.0f - s) : 0.5f * s;
+}
+// common_math.cuh:453-465
+DMT_DEV void gram_schmidt(f3 n, f3& a, f3& b) {
+  if (fabsf(n.x - n.y) > 1e-3f || fabsf(n.x - n.z) > 1e-3f)
+    a = mk3(n.z - n.y, n.x - n.z, n.y - n.x);
+  else
+    a = mk3(n.z - n.y, n.x + n.z, -n.y - n.x);
+  a = normalize(a);
+  b = cross(n, a);
+}
+DMT_DEV void orthonormal_tangent(f3 n, f3 t, f3& a, f3& b) {  // :466-472
+  b = normalize(cross(n, t));
+  a = cross(b, n);
+}
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.318309886183790671538f;
+constexpr float kInf = __builtin_huge_valf();
+
+// ---------------------------------------------------------------------------------------------
+// fp16 storage codec.  The reference quantises BSDF terms to fp16 every bounce
+// (CC/private/bsdf.cu:424,948-950,963).  Its host branch rounds half UP, not to nearest even
+// (CC/private/encoding.cu:93-115); that branch is the one the oracle follows, so it is
+// reproduced bit for bit here with integer ops instead of v_cvt_f16_f32.
+// ---------------------------------------------------------------------------------------------
+DMT_DEV uint32_t f2h(float f) {
+  uint32_t const u = __float_as_uint(f);
+  uint32_t const sign = (u >> 16) & 0x8000u;
+  int32_t exp = int32_t((u >> 23) & 0xFFu) - 112;
+  uint32_t mant = u & 0x007FFFFFu;
+  if (exp >= 31) return sign | 0x7C00u | (mant ? 0x200u : 0u);
+  if (exp <= 0) {
+    if (exp < -10) return sign;
+    mant |= 0x00800000u;
+    uint32_t const shift = uint32_t(14 - exp);
+    return sign | (((mant >> shift) + ((mant >> (shift - 1)) & 1u)) & 0xFFFFu);
+  }
+  uint32_t rounded = mant + 0x00001000u;
+  if (rounded & 0x00800000u) {
+    rounded = 0;
+    exp += 1;
+    if (exp >= 31) return sign | 0x7C00u;
+  }
+  return sign | (uint32_t(exp) << 10) | (rounded >> 13);
+}
+DMT_DEV float h2f(uint32_t h) {  // exact; v_cvt_f32_f16 with fp16 denormals enabled
+  _Float16 hv = __builtin_bit_cast(_Float16, (unsigned short)(h & 0xFFFFu));
+  return float(hv);
+}
+DMT_DEV float q16(float f) { return h2f(f2h(f)); }
+DMT_DEV f3 q16(f3 v) { return mk3(q16(v.x), q16(v.y), q16(v.z)); }
+
+// octahedral decode                                             CC/private/encoding.cu:39-60
+DMT_DEV float sign_pm1(float f) { return __builtin_signbit(f) ? -1.f : 1.f; }
+DMT_DEV f3 dir_from_octa(uint32_t octa) {
+  float const mx = 65535.f;
+  float const fx = float(octa & 0xFFFFu) / mx * 2.f - 1.f;
+  float const fy = float((octa >> 16) & 0xFFFFu) / mx * 2.f - 1.f;
+  f3 n = mk3(fx, fy, 1.f - fabsf(fx) - fabsf(fy));
+  float const nx = n.x, ny = n.y;
+  // flip * a + !flip * b with flip in {0,1}: the dropped product is an exact +-0 addend
+  if (n.z < 0.f) {
+    n.x = 1.f * (1.f - fabsf(ny)) * sign_pm1(nx) + 0.f * nx;
+    n.y = 1.f * (1.f - fabsf(nx)) * sign_pm1(ny) + 0.f * ny;
+  } else {
+    n.x = 0.f * (1.f - fabsf(ny)) * sign_pm1(nx) + 1.f * nx;
+    n.y = 0.f * (1.f - fabsf(nx)) * sign_pm1(ny) + 1.f * ny;
+  }
+  return normalize(n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// scene records
+// ---------------------------------------------------------------------------------------------
+struct Rec32 {  // packed BSDF / Light record, 8 dwords
+  uint32_t w[8];
+};
+DMT_DEV uint32_t lo16(uint32_t w) { return w & 0xFFFFu; }
+DMT_DEV uint32_t hi16(uint32_t w) { return w >> 16; }
+
+// hot-loop triangle record, built on the host at upload: p0, e0 = p1-p0, e1 = p2-p0 (same float
+// subtractions the reference does per test, CC/private/shapes.cu:10-11)
+struct TriIsect {  // 48 B, three 16-byte loads
+  float p0x, p0y, p0z, e0x;
+  float e0y, e0z, e1x, e1y;
+  float e1z;
+  uint32_t matId;
+  uint32_t pad0, pad1;
+};
+// post-hit record: original vertices (error bound needs them) + unit geometric normal
+// normalize(cross(e1,e0)) precomputed on the host with the same IEEE expression (shapes.cu:48)
+struct TriPost {  // 64 B
+  float p0x, p0y, p0z, p1x;
+  float p1y, p1z, p2x, p2y;
+  float p2z, nx, ny, nz;
+  uint32_t matId, pad0, pad1, pad2;
+};
+
+struct CameraXf {  // the matrix entries the perspective path needs (column-major m[16])
+  float cfr[16];   // cameraFromRaster
+  float rfc[16];   // renderFromCamera
+};
+
+struct SamplerParams {  // CC types.cuh:93-97
+  int32_t scale0, scale1;
+  int32_t exp0, exp1;
+  int32_t inv0, inv1;
+};
+
+struct SceneView {
+  TriIsect const* __restrict__ tris;
+  TriPost const* __restrict__ post;
+  Rec32 const* __restrict__ bsdfs;
+  Rec32 const* __restrict__ lights;
+  Rec32 const* __restrict__ infLights;
+  uint32_t triCount;
+  uint32_t bsdfCount;
+  uint32_t lightCount;
+  uint32_t infLightCount;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Halton-Owen sampler                                             CC/private/rng.cu:48-262
+// Every number is a pure function of (pixel, sample, dimension); dimensions cycle through 2..9
+// (rng.cu:236,246), so a path can only ever see 8 distinct values.  They are computed once per
+// sample with compile-time bases (constant division -> mul_hi), and later draws are register
+// selects.
+// ---------------------------------------------------------------------------------------------
+DMT_DEV uint32_t mix_bits32(uint32_t v) {  // rng.cu:61-68
+  v ^= v >> 16;
+  v *= 0x7feb352dU;
+  v ^= v >> 15;
+  v *= 0x846ca68bU;
+  v ^= v >> 16;
+  return v;
+}
+template <uint32_t BASE>
+DMT_DEV float owen_radical_inverse(uint32_t index, uint32_t seed) {  // rng.cu:137-173
+  float const invBase = 1.0f / float(BASE);  // correctly rounded at compile time (= __frcp_rn)
+  float result = 0.0f;
+  float invBasePow = invBase;
+  uint32_t revHash = 0;
+  while (index > 0) {
+    uint32_t const next = index / BASE;
+    uint32_t const digit = index - next * BASE;
+    uint32_t const scramble = mix_bits32(seed ^ revHash);
+    uint32_t const permuted = (digit + scramble) % BASE;  // 32-bit wraparound, as the reference
+    result = __builtin_fmaf(float(permuted), invBasePow, result);
+    revHash = revHash * BASE + digit;
+    invBasePow *= invBase;
+    index = next;
+  }
+  return fminf(result, 0.99999994f);
+}
+template <uint32_t BASE>
+DMT_DEV float radical_inverse(uint32_t index) {  // rng.cu:70-94
+  float const invBase = 1.0f / float(BASE);
+  float result = 0.0f;
+  float invBasePow = invBase;
+  while (index > 0) {
+    uint32_t const next = index / BASE;
+    uint32_t const digit = index - next * BASE;
+    result = __builtin_fmaf(float(digit), invBasePow, result);
+    invBasePow *= invBase;
+    index = next;
+  }
+  return fminf(result, 0.99999994f);
+}
+template <int DIM, uint32_t BASE>
+DMT_DEV float sample_dim(uint32_t haltonIndex) {  // rng.cu:175-178
+  uint32_t const seed = mix_bits32(1u + (uint32_t(DIM) << 4));
+  return owen_radical_inverse<BASE>(haltonIndex, seed);
+}
+
+// Halton index of sample 0 of a pixel (rng.cu:216-228); add s * stride for sample s
+DMT_DEV int32_t halton_pixel_base(SamplerParams const& p, int px, int py) {
+  int const stride = p.scale0 * p.scale1;
+  int const pmx = px % 128, pmy = py % 128;
+  // inverseRadicalInverse(pm, base, nDigits), rng.cu:48-59
+  int32_t inv0 = 0, t = pmx;
+  for (int i = 0; i < p.exp0; ++i) {
+    inv0 = inv0 * 2 + (t % 2);
+    t /= 2;
+  }
+  int32_t inv1 = 0;
+  t = pmy;
+  for (int i = 0; i < p.exp1; ++i) {
+    inv1 = inv1 * 3 + (t % 3);
+    t /= 3;
+  }
+  int32_t idx = 0;
+  idx += inv0 * (stride / p.scale0) * p.inv0;
+  idx += inv1 * (stride / p.scale1) * p.inv1;
+  idx %= stride;
+  return idx;
+}
+
+struct Sampler {
+  float u0, u1, u2, u3, u4, u5, u6, u7;  // sampleDim(2..9, haltonIndex)
+  int dim;
+
+  DMT_DEV void start(uint32_t haltonIndex) {
+    u0 = sample_dim<2, 5>(haltonIndex);
+    u1 = sample_dim<3, 7>(haltonIndex);
+    u2 = sample_dim<4, 11>(haltonIndex);
+    u3 = sample_dim<5, 13>(haltonIndex);
+    u4 = sample_dim<6, 17>(haltonIndex);
+    u5 = sample_dim<7, 19>(haltonIndex);
+    u6 = sample_dim<8, 23>(haltonIndex);
+    u7 = sample_dim<9, 29>(haltonIndex);
+    dim = 2;
+  }
+  DMT_DEV float pick(int d) const {  // d in 2..9
+    float r = u0;
+    r = d == 3 ? u1 : r;
+    r = d == 4 ? u2 : r;
+    r = d == 5 ? u3 : r;
+    r = d == 6 ? u4 : r;
+    r = d == 7 ? u5 : r;
+    r = d == 8 ? u6 : r;
+    r = d == 9 ? u7 : r;
+    return r;
+  }
+  DMT_DEV float get1D() {  // rng.cu:233-240
+    if (dim >= 10) dim = 2;
+    int const d = dim++;
+    return pick(d);
+  }
+  DMT_DEV f2 get2D() {  // rng.cu:242-252
+    if (dim + 1 >= 10) dim = 2;
+    int const d = dim;
+    dim += 2;
+    return mk2(pick(d), pick(d + 1));
+  }
+};
+// getPixel2D, rng.cu:254-262.  Base 2: every partial sum of distinct powers of two with <= 24
+// significant bits is exact, so the fmaf chain equals bit reversal.
+DMT_DEV f2 pixel2d(SamplerParams const& p, int32_t haltonIndex) {
+  uint32_t const a = uint32_t(haltonIndex >> p.exp0);
+  float const rx = fminf(float(__brev(a)) * 2.3283064365386963e-10f, 0.99999994f);
+  float const ry = radical_inverse<3>(uint32_t(haltonIndex / p.scale1));
+  return mk2(rx, ry);
+}
+
+// ---------------------------------------------------------------------------------------------
+// camera                                   CC/private/extra_math.cu:7-42, common_math.cu:80-102
+// ---------------------------------------------------------------------------------------------
+struct Ray {
+  f3 o, d;
+};
+DMT_DEV f3 xf_point(float const* m, f3 p) {
+  float x = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
+  float y = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
+  float z = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14];
+  float const w = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15];
+  if (w != 1.0f && w != 0.0f) {
+    float const iw = 1.0f / w;
+    x *= iw, y *= iw, z *= iw;
+  }
+  return mk3(x, y, z);
+}
+DMT_DEV f3 xf_dir(float const* m, f3 v) {
+  return mk3(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z,
+             m[2] * v.x + m[6] * v.y + m[10] * v.z);
+}
+DMT_DEV Ray camera_ray(CameraXf const& cam, SamplerParams const& sp, int px, int py,
+                       int32_t haltonIndex) {
+  f2 const r = pixel2d(sp, haltonIndex);
+  // (getPixel2D - 0.5) + 0.5 + pixel, left to right (extra_math.cu:10-12)
+  float const fx = ((r.x - 0.5f) + 0.5f) + float(px);
+  float const fy = ((r.y - 0.5f) + 0.5f) + float(py);
+  f3 const pCamera = xf_point(cam.cfr, mk3(fx, fy, 0.0f));
+  Ray ray;
+  ray.o = xf_point(cam.rfc, mk3(0.f, 0.f, 0.f));
+  ray.d = normalize(xf_dir(cam.rfc, pCamera));
+  return ray;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Moeller-Trumbore, two-sided                                    CC/private/shapes.cu:5-57
+// Returns validity and (t,u,v); position / normal / error bound are rebuilt once for the
+// winning triangle only (hit_finish) instead of per candidate.
+// ---------------------------------------------------------------------------------------------
+struct MTResult {
+  bool valid;
+  float t, u, v;
+};
+DMT_DEV MTResult mt_test(f3 p0, f3 e0, f3 e1, Ray const& ray) {
+  f3 const dxe1 = mk3(ray.d.y * e1.z - ray.d.z * e1.y, ray.d.z * e1.x - ray.d.x * e1.z,
+                      ray.d.x * e1.y - ray.d.y * e1.x);
+  float const det = dxe1.x * e0.x + dxe1.y * e0.y + dxe1.z * e0.z;
+  float const invDet = 1.0f / det;
+  f3 const ov = mk3(ray.o.x - p0.x, ray.o.y - p0.y, ray.o.z - p0.z);
+  f3 const txe0 = mk3(ov.y * e0.z - ov.z * e0.y, ov.z * e0.x - ov.x * e0.z,
+                      ov.x * e0.y - ov.y * e0.x);
+  float const u = invDet * (dxe1.x * ov.x + dxe1.y * ov.y + dxe1.z * ov.z);
+  float const v = invDet * (txe0.x * ray.d.x + txe0.y * ray.d.y + txe0.z * ray.d.z);
+  float const t = invDet * (txe0.x * e1.x + txe0.y * e1.y + txe0.z * e1.z);
+  float const tol = 1e-7f;
+  MTResult r;
+  r.valid = !(fabsf(det) < tol) && (u >= -tol && v >= -tol && (u + v) <= 1 + tol) && (t > 1e-4f);
+  r.t = t, r.u = u, r.v = v;
+  return r;
+}
+DMT_DEV MTResult mt_test(TriIsect const& T, Ray const& ray) {
+  return mt_test(mk3(T.p0x, T.p0y, T.p0z), mk3(T.e0x, T.e0y, T.e0z), mk3(T.e1x, T.e1y, T.e1z), ray);
+}
+
+struct Hit {
+  f3 pos, normal, error;
+  uint32_t matId;
+};
+DMT_DEV float gamma7() {  // CC extra_math.cuh:21-29, gamma(7)
+  float const f = 7.f * 1.1920928955078125e-07f * 0.5f;
+  return f / (1 - f);
+}
+DMT_DEV Hit hit_finish(TriPost const& P, float u, float v, f3 rayDir) {
+  f3 const p0 = mk3(P.p0x, P.p0y, P.p0z);
+  f3 const p1 = mk3(P.p1x, P.p1y, P.p1z);
+  f3 const p2 = mk3(P.p2x, P.p2y, P.p2z);
+  f3 const e0 = mk3(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z);
+  f3 const e1 = mk3(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z);
+  Hit h;
+  h.pos = p0 + u * e0 + v * e1;                                                // shapes.cu:47
+  h.error = gamma7() * (abs3(u * p0) + abs3(v * p1) + abs3((1 - u - v) * p2));  // :53
+  f3 n = mk3(P.nx, P.ny, P.nz);
+  if (dot(rayDir, n) > 0) n = -n;  // T/megakernel/megakernel.cu:129-131
+  h.normal = n;
+  h.matId = P.matId;
+  return h;
+}
+// CC extra_math.cuh:36-59
+DMT_DEV f3 offset_ray_origin(f3 p, f3 error, f3 ng, f3 w) {
+  float const d = dot(abs3(ng), error);
+  f3 offset = ng * d;
+  if (dot(w, ng) < 0.f) offset = -offset;
+  f3 po = p + offset;
+  po.x = nextafterf(po.x, offset.x > 0 ? kInf : -kInf);
+  po.y = nextafterf(po.y, offset.y > 0 ? kInf : -kInf);
+  po.z = nextafterf(po.z, offset.z > 0 ? kInf : -kInf);
+  return po;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampling helpers                                               CC/private/sampling.cu
+// ---------------------------------------------------------------------------------------------
+DMT_DEV f2 sample_uniform_disk(f2 u) {  // :135-155 (the 3pi/4 branch is the reference's)
+  float const a = 2.f * u.x - 1.f;
+  float const b = 2.f * u.y - 1.f;
+  if (a == 0.f && b == 0.f) return mk2(0.f, 0.f);
+  float rho, phi;
+  if (fabsf(a) > fabsf(b)) {
+    rho = a;
+    phi = (kPi / 4) * (b / a);
+  } else {
+    rho = b;
+    phi = (3 * kPi / 4) * (a / b);
+  }
+  return mk2(rho * cosf(phi), rho * sinf(phi));
+}
+DMT_DEV f3 sample_cos_hemisphere(f3 n, f2 u, float& pdf) {  // :157-167
+  f2 const r = sample_uniform_disk(u);
+  float const cosTheta = safe_sqrt(1.f - dot(r, r));
+  f3 T, B;
+  gram_schmidt(n, T, B);
+  pdf = cosTheta * kInvPi;
+  return r.x * T + r.y * B + cosTheta * n;
+}
+DMT_DEV f3 sample_uniform_sphere(f2 rnd) {  // :123-133
+  float const z = 1.0f - 2.0f * rnd.x;
+  float const r = safe_sqrt(1.f - z * z);
+  float const phi = 2 * kPi * rnd.y;
+  return mk3(r * cosf(phi), r * sinf(phi), z);
+}
+// :86-121.  `xy *= s` in the reference assigns s to both components (common_math.cuh:349-353).
+DMT_DEV f3 sample_uniform_cone(f3 N, float omc, f2 rnd, float& cosTheta, float& pdf, int& delta) {
+  if (omc > 0) {
+    f2 const xy = sample_uniform_disk(rnd);
+    float const r2 = dot(xy, xy);
+    cosTheta = 1.0f - r2 * omc;
+    float const s = safe_sqrt(r2 * omc * (2.0f - r2 * omc));
+    pdf = 0.5f / (kPi * fmaxf(omc, 1e-8f));
+    f3 T, B;
+    gram_schmidt(N, T, B);
+    return s * T + s * B + cosTheta * N;
+  }
+  delta = 1;
+  cosTheta = 1.0f;
+  pdf = 1.0f;
+  return N;
+}
+DMT_DEV bool ray_sphere(f3 o, f3 d, float tMin, float tMax, f3 C, float radius, f3& ip, float& it) {
+  f3 const dv = C - o;  // :51-84
+  float const r_sq = radius * radius;
+  float const d_sq = dot(dv, dv);
+  float const dcos = dot(dv, d);
+  if (d_sq > r_sq && dcos < 0.0f) return false;
+  f3 const perp = dv - dcos * d;
+  float const dsin_sq = dot(perp, perp);
+  if (dsin_sq > r_sq) return false;
+  float const t = dcos - copysignf(sqrtf(r_sq - dsin_sq), d_sq - r_sq);
+  if (t > tMin && t < tMax) {
+    it = t;
+    ip = o + d * t;
+    return true;
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lights                                                          CC/private/light.cu
+// record layout CC/public/cuda-core/light.cuh:10-49 (dword view):
+//   w0 = I.x | I.y<<16, w1 = I.z | type<<16, w2..w4 = pos (point/spot)
+//   point: w5.lo = radius;  spot: w5 = octa dir, w6 = cosTheta0 | cosThetaE<<16, w7.lo = radius
+//   directional: w2 = octa dir, w3.lo = oneMinusCosAngle
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t { LT_POINT = 0, LT_SPOT = 1, LT_ENV = 2, LT_DIR = 3 };
+struct LightSample {
+  f3 pLight, direction;
+  float pdf;
+  int delta;
+  float distance;
+  float factor;
+  DMT_DEV bool valid() const {  // light.cuh:65-67
+    return direction.x != 0 && direction.y != 0 && direction.z != 0 && pdf != 0;
+  }
+};
+DMT_DEV uint32_t light_type(Rec32 const& L) { return hi16(L.w[1]); }
+DMT_DEV f3 light_intensity(Rec32 const& L) {
+  return mk3(h2f(lo16(L.w[0])), h2f(hi16(L.w[0])), h2f(lo16(L.w[1])));
+}
+DMT_DEV f3 light_pos(Rec32 const& L) {
+  return mk3(__uint_as_float(L.w[2]), __uint_as_float(L.w[3]), __uint_as_float(L.w[4]));
+}
+DMT_DEV LightSample sample_point_light(Rec32 const& L, f3 position, f2 u, bool hadT, f3 normal) {
+  LightSample s{};  // light.cu:13-80
+  s.factor = 1.0f;
+  float const radius = h2f(lo16(L.w[5]));
+  float const radiusSqr = sqr(radius);
+  f3 lightN = position - light_pos(L);
+  float const distSqr = dot(lightN, lightN);
+  float const dist = sqrtf(distSqr);
+  lightN = lightN / dist;
+  bool const effDelta = (radius / dist) < 1e-3f;
+  float cosTheta = 0.f;
+  if (distSqr > radiusSqr) {
+    float const omc = sin_sqr_to_one_minus_cos(radiusSqr / distSqr);
+    s.direction = sample_uniform_cone(-lightN, omc, u, cosTheta, s.pdf, s.delta);
+    if (effDelta || s.delta) {
+      s.pdf = 1;
+      s.delta = 1;
+    }
+  } else {
+    if (hadT) {
+      s.direction = sample_uniform_sphere(u);
+      s.pdf = 0.25f * kInvPi;
+    } else {
+      s.direction = sample_cos_hemisphere(normal, u, s.pdf);
+    }
+    cosTheta = -dot(s.direction, lightN);
+  }
+  s.distance = dist * cosTheta -
+               copysignf(safe_sqrt(radiusSqr - distSqr + distSqr * cosTheta * cosTheta),
+                         distSqr - radiusSqr);
+  s.pLight = position + s.direction * s.distance;
+  return s;
+}
+DMT_DEV LightSample sample_spot_light(Rec32 const& L, f3 position, f2 u, bool hadT, f3 normal) {
+  LightSample s{};  // light.cu:110-205
+  float const fltMax = 3.402823466e+38f;
+  s.distance = fltMax;
+  float const radius = h2f(lo16(L.w[7]));
+  float const cosThetaE = h2f(hi16(L.w[6]));
+  f3 const spotDir = normalize(dir_from_octa(L.w[5]));
+  f3 const lpos = light_pos(L);
+  float const radiusSqr = radius * radius;
+  f3 lightN = position - lpos;
+  float const distSqr = dot(lightN, lightN);
+  float const dist = sqrtf(distSqr);
+  lightN = lightN / dist;
+  bool const effDelta = (radius / dist) < 1e-3f;
+  bool outside = false;
+  float cosTheta = 0.f;
+  if (distSqr > radiusSqr) {
+    float const omcSpread = 1.f - cosThetaE;
+    float const omcHalf = sin_sqr_to_one_minus_cos(radiusSqr / distSqr);
+    if (omcHalf < omcSpread) {
+      s.direction = sample_uniform_cone(-lightN, omcHalf, u, cosTheta, s.pdf, s.delta);
+    } else {
+      s.direction = sample_uniform_cone(-spotDir, omcSpread, u, cosTheta, s.pdf, s.delta);
+      if (!ray_sphere(position, s.direction, 0.f, fltMax, lpos, radius, s.pLight, s.distance)) {
+        outside = true;
+        s.pdf = 0;
+      }
+    }
+  } else {
+    if (hadT) {
+      s.direction = sample_uniform_sphere(u);
+      s.pdf = 0.25f * kInvPi;
+    } else {
+      s.direction = sample_cos_hemisphere(normal, u, s.pdf);
+    }
+    cosTheta = -dot(s.direction, lightN);
+  }
+  if (!outside) {
+    // spotLightAttenuation -> smoothstep(a,b,x) clamps with fmaxf(fminf(.,0),1), i.e. t == 1 for
+    // every input including NaN, so the factor is exactly 1 (light.cuh:77-81,
+    // common_math.cuh:484-489); the local-frame transform feeding it is dead and not computed.
+    s.factor = 1.f;
+    if (s.distance == fltMax) {
+      s.distance = dist * cosTheta *
+                   copysignf(safe_sqrt(radiusSqr - distSqr + distSqr * cosTheta * cosTheta),
+                             distSqr - radiusSqr);  // light.cu:176-179 (product, as written)
+    }
+    if (effDelta) {
+      s.pdf = 1.f;
+      s.delta = 1;
+    }
+    s.pLight = position + s.direction * s.distance;
+    f3 const ng = normalize(s.pLight - lpos);
+    s.pLight = ng * radius + lpos;
+    f3 const newDir = s.pLight - position;
+    float const distance = sqrtf(newDir.x * newDir.x + newDir.y * newDir.y + newDir.z * newDir.z);
+    s.direction = newDir / distance;
+    s.distance = distance;
+  }
+  return s;
+}
+DMT_DEV LightSample sample_light(Rec32 const& L, f3 position, f2 u, bool hadT, f3 normal) {
+  LightSample s{};  // light.cu:211-253
+  uint32_t const type = light_type(L);
+  if (type == LT_SPOT) {
+    s = sample_spot_light(L, position, u, hadT, normal);
+  } else if (type == LT_POINT) {
+    s = sample_point_light(L, position, u, hadT, normal);
+  } else if (type == LT_ENV) {
+    s.direction = sample_uniform_sphere(u);
+    s.pdf = 0.25f * kInvPi;
+    s.factor = 1.f;
+    s.pLight = s.direction;
+    s.distance = 3.402823466e+38f;
+  } else if (type == LT_DIR) {
+    float unused = 0.f;
+    s.pLight = sample_uniform_cone(dir_from_octa(L.w[2]), h2f(lo16(L.w[3])), u, unused, s.pdf,
+                                   s.delta);
+    s.direction = -s.pLight;
+    s.factor = 1.f;
+    s.delta = 1;
+    s.distance = 3.402823466e+38f;
+  }
+  return s;
+}
+DMT_DEV f3 eval_light(Rec32 const& L, LightSample const& ls) {  // light.cu:309-320
+  f3 Le = light_intensity(L) * ls.factor;
+  uint32_t const t = light_type(L);
+  if (t == LT_POINT || t == LT_SPOT) Le = Le / (ls.distance * ls.distance);
+  return Le;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BSDFs                      CC/public/cuda-core/bsdf.cuh, CC/private/bsdf.cu
+// record layout bsdf.cuh:18-73 (dword view):
+//   w0 = W.x | W.y<<16, w1 = W.z | type<<16
+//   Oren-Nayar: w2.lo..w3.lo albedo (unused), w3.hi,w4.lo,w4.hi multiScatter, w5.lo roughness,
+//               w5.hi = a, w6.lo = b
+//   GGX: w2 = energyScale (f32), w3 = phi0 | alphax<<16, w4.lo = alphay
+//        dielectric: w4.hi = eta, w5.lo,w5.hi,w6.lo reflectanceTint, w6.hi,w7.lo,w7.hi transTint
+//        conductor:  w4.hi,w5.lo,w5.hi eta, w6.lo,w6.hi,w7.lo kappa
+// The reference mutates the packed record per hit (prepareBSDF) and re-reads it; here the
+// record is decoded once into registers and every fp16 store of the reference becomes q16().
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t { BS_OREN = 0, BS_GGX_DIEL = 1, BS_GGX_COND = 2, BS_LAMBERT = 3 };
+
+__constant__ float c_ggxE[DMT_GGX_E_ROWS * DMT_GGX_E_COLS] = {DMT_GGX_E_TABLE_VALUES};
+__constant__ float c_ggxEavg[DMT_GGX_EAVG_COUNT] = {DMT_GGX_EAVG_TABLE_VALUES};
+
+DMT_DEV float table_read(float const* table, float x, int size) {  // CC extra_math.cu:95-109
+  x = fminf(fmaxf(x, 0.f), 1.f) * float(size - 1);
+  int const index = int(fminf(float(int(x)), float(size - 1)));
+  int const nIndex = int(fminf(float(index + 1), float(size - 1)));
+  float const t = x - float(index);
+  float const d0 = table[index];
+  if (t == 0.f) return d0;
+  float const d1 = table[nIndex];
+  return (1.f - t) * d0 + t * d1;
+}
+DMT_DEV float table_read_2d(float const* table, float x, float y, int sx, int sy) {  // :111-126
+  y = fminf(fmaxf(y, 0.f), 1.f) * float(sy - 1);
+  int const index = int(fminf(float(int(y)), float(sy - 1)));
+  int const nIndex = int(fminf(float(index + 1), float(sy - 1)));
+  float const t = y - float(index);
+  float const d0 = table_read(table + sx * index, x, sx);
+  if (t == 0.f) return d0;
+  float const d1 = table_read(table + sx * nIndex, x, sx);
+  return (1.f - t) * d0 + t * d1;
+}
+
+struct Bsdf {  // decoded + prepared, registers only
+  uint32_t type;
+  f3 weight;
+  // Oren-Nayar: a, b, ms.   GGX: escale, ax, ay, phi0, iso, and {eta, rt, tt} or {eta3, kappa3}
+  float a, b;
+  f3 ms;
+  float escale, ax, ay, phi0;
+  bool iso;
+  float eta;
+  f3 c0, c1;  // dielectric: reflectanceTint, transmittanceTint; conductor: eta, kappa
+};
+
+DMT_DEV float fresnel_dielectric(float cosI, float eta, float& cosT_out) {  // bsdf.cuh:175-202
+  cosI = fmaxf(-1.f, fminf(1.f, cosI));
+  if (!(cosI > 0.f)) {
+    eta = 1.f / eta;
+    cosI = fabsf(cosI);
+  }
+  float const sinI = safe_sqrt(fmaxf(0.f, 1.f - cosI * cosI));
+  float const sinT = sinI / eta;
+  if (sinT >= 1.f) return 1.f;
+  float const cosT = safe_sqrt(fmaxf(0.f, 1.f - sinT * sinT));
+  cosT_out = cosT;
+  float const rParl = ((eta * cosI) - (cosT)) / ((eta * cosI) + (cosT));
+  float const rPerp = ((cosI) - (eta * cosT)) / ((cosI) + (eta * cosT));
+  return (rParl * rParl + rPerp * rPerp) * 0.5f;
+}
+DMT_DEV f3 fresnel_conductor(float cosI, f3 eta, f3 k) {  // bsdf.cuh:204-224
+  cosI = fmaxf(-1.f, fminf(1.f, cosI));
+  float const c2 = cosI * cosI;
+  float const s2 = 1.f - c2;
+  f3 const eta2 = eta * eta;
+  f3 const k2 = k * k;
+  f3 const t0 = eta2 - k2 - s2;
+  f3 const a2b2 = sqrt3(t0 * t0 + 4.f * eta2 * k2);
+  f3 const t1 = a2b2 + c2;
+  f3 const a = sqrt3(0.5f * (a2b2 + t0));
+  f3 const t2 = 2.f * cosI * a;
+  f3 const Rs = (t1 - t2) / (t1 + t2);
+  f3 const t3 = c2 * a2b2 + s2 * s2;
+  f3 const t4 = t2 * s2;
+  f3 const Rp = Rs * (t3 - t4) / (t3 + t4);
+  return 0.5f * (Rp + Rs);
+}
+DMT_DEV void microfacet_fresnel(Bsdf const& b, float cos_HO, float& cos_HI, f3& R, f3& T) {
+  if (b.type == BS_GGX_DIEL) {  // bsdf.cu:331-354
+    float const F = fresnel_dielectric(cos_HO, b.eta, cos_HI);
+    R = F * b.c0;
+    T = (1.f - F) * b.c1;
+  } else {
+    R = fresnel_conductor(cos_HO, b.c0, b.c1);
+    T = mk3(0, 0, 0);
+  }
+}
+DMT_DEV float oren_nayar_G(float cosTheta) {  // bsdf.cu:751-763
+  float const piOver2 = kPi / 2;
+  float const twoThirds = 2.f / 3.f;
+  float const piOver2m = piOver2 - twoThirds;
+  if (cosTheta < 1e-6f) return piOver2m - cosTheta;
+  float const sinTheta = sin_from_cos(cosTheta);
+  float const theta = safe_acos(cosTheta);
+  return sinTheta * (theta - twoThirds - sinTheta * cosTheta) +
+         twoThirds * (sinTheta / cosTheta) * (1.f - sqr(sinTheta) * sinTheta);
+}
+
+// decode + prepareBSDF (bsdf.cu:909-1011) in one step
+DMT_DEV Bsdf bsdf_prepare(Rec32 const& r, f3 ns, f3 wo) {
+  Bsdf b{};
+  b.type = hi16(r.w[1]);
+  b.weight = mk3(h2f(lo16(r.w[0])), h2f(hi16(r.w[0])), h2f(lo16(r.w[1])));
+  if (b.type == BS_OREN) {
+    b.a = h2f(hi16(r.w[5]));
+    b.b = h2f(lo16(r.w[6]));
+    float const nl = fmaxf(0.f, dot(ns, wo));
+    float const Ev = b.a * kPi + b.b * oren_nayar_G(nl);
+    f3 ms = b.weight * (1.f - Ev);
+    ms = mk3(fmaxf(ms.x, 0.f), fmaxf(ms.y, 0.f), fmaxf(ms.z, 0.f));
+    b.ms = q16(ms);
+  } else if (b.type == BS_GGX_DIEL || b.type == BS_GGX_COND) {
+    b.phi0 = float(lo16(r.w[3])) / 65535 * 2.f * kPi;  // bsdf.cuh:52-55
+    uint32_t const axq = hi16(r.w[3]), ayq = lo16(r.w[4]);
+    b.iso = axq == ayq;
+    b.ax = float(axq) / 65535;
+    b.ay = float(ayq) / 65535;
+    f3 Fss;
+    if (b.type == BS_GGX_DIEL) {
+      b.eta = h2f(hi16(r.w[4]));
+      b.c0 = mk3(h2f(lo16(r.w[5])), h2f(hi16(r.w[5])), h2f(lo16(r.w[6])));
+      b.c1 = mk3(h2f(hi16(r.w[6])), h2f(lo16(r.w[7])), h2f(hi16(r.w[7])));
+      Fss = b.c1;
+    } else {
+      b.c0 = mk3(h2f(hi16(r.w[4])), h2f(lo16(r.w[5])), h2f(hi16(r.w[5])));
+      b.c1 = mk3(h2f(lo16(r.w[6])), h2f(hi16(r.w[6])), h2f(lo16(r.w[7])));
+    }
+    {
+      float const cos_HO = fabsf(dot(wo, ns));
+      float unused = 0.f;
+      f3 R, T;
+      microfacet_fresnel(b, cos_HO, unused, R, T);
+      b.weight = q16(R + T);  // setWeight -> fp16
+    }
+    if (b.type == BS_GGX_COND) {  // F82-tint, bsdf.cu:981-992
+      f3 const F0 = fresnel_conductor(1.f, b.c0, b.c1);
+      f3 const F82 = fresnel_conductor(1.f / 7.f, b.c0, b.c1);
+      f3 const B = (lerp3(F0, mk3(1, 1, 1), 0.46266436f) - F82) * 17.651384f;
+      Fss = lerp3(F0, mk3(1, 1, 1), 1.f / 21.f) - B * (1.f / 126.f);
+    }
+    float const alpha2 = b.ax * b.ay;
+    float const cos_NO = fmaxf(0.f, dot(ns, wo));
+    // energyPreservingGGXScale, bsdf.cu:407-426 (software table lookup = the host branch)
+    float const E = table_read_2d(c_ggxE, alpha2, cos_NO, DMT_GGX_E_COLS, DMT_GGX_E_ROWS);
+    float const Eavg = table_read(c_ggxEavg, alpha2, DMT_GGX_EAVG_COUNT);
+    float const missing = (1.f - E) / E;
+    b.escale = 1.f + missing;
+    f3 const Fms = Fss * Eavg / (mk3(1, 1, 1) - Fss * (1.f - Eavg));
+    b.weight = q16(b.weight * (1.f + Fms * missing) / b.escale);
+  }
+  return b;
+}
+
+struct BsdfSample {
+  f3 wi, f;
+  float pdf, eta;
+  bool delta, refract;
+  DMT_DEV bool valid() const { return wi.x != 0 && wi.y != 0 && wi.z != 0 && pdf != 0.f; }
+};
+
+DMT_DEV f3 oren_nayar_intensity(Bsdf const& b, f3 n, f3 v, f3 l) {  // bsdf.cu:765-788
+  float const nl = fmaxf(dot(n, l), 0.f);
+  if (b.b <= 0) {
+    float const r = nl * kInvPi;
+    return mk3(r, r, r);
+  }
+  float const nv = fmaxf(dot(n, v), 0.f);
+  float t = dot(l, v) - nl * nv;
+  if (t > 0.f) t /= fmaxf(nl, nv) + 1.175494351e-38f;
+  float const single = b.a + b.b * t;
+  float const El = b.a * kPi + b.b * oren_nayar_G(nl);
+  f3 const multi = b.ms * (1.f - El);
+  return nl * (single + multi);
+}
+DMT_DEV f3 tangent_from_phi(f3 ns, float phi0) {  // bsdf.cu:279-294
+  f3 const ref = fabsf(ns.x) < 0.999f ? mk3(1.0f, 0.0f, 0.0f) : mk3(0.0f, 1.0f, 0.0f);
+  f3 const t = normalize(cross(ref, ns));
+  f3 const bt = cross(ns, t);
+  float const s = sinf(phi0);
+  float const c = cosf(phi0);
+  return c * t + s * bt;
+}
+DMT_DEV f3 sample_ggx_vndf(f3 wo, f2 u, float ax, float ay) {  // bsdf.cu:303-329
+  f3 const V = normalize(mk3(ax * wo.x, ay * wo.y, wo.z));
+  f3 T1, T2;
+  float const lensq = V.x * V.x + V.y * V.y;
+  if (lensq > 1e-7f) {
+    float const invLen = rsqrt_ieee(lensq);
+    T1 = mk3(-V.y * invLen, V.x * invLen, 0.f);
+    T2 = cross(V, T1);
+  } else {
+    T1 = mk3(1, 0, 0);
+    T2 = mk3(0, 1, 0);
+  }
+  f2 t = sample_uniform_disk(u);
+  t.y = lerp1(safe_sqrt(1.f - t.x * t.x), t.y, 0.5f * (1.f + V.z));
+  f3 Nh = t.x * T1 + t.y * T2 + safe_sqrt(1.f - dot(t, t)) * V;
+  Nh = normalize(mk3(ax * Nh.x, ay * Nh.y, fmaxf(0.f, Nh.z)));
+  return Nh;
+}
+DMT_DEV float ggx_lambda_from(float x) { return 0.5f * (sqrtf(1.f + x) - 1.f); }
+DMT_DEV float ggx_D(float alpha2, float cos_NH) {
+  float const c2 = fminf(cos_NH * cos_NH, 1.f);
+  float const omc2 = 1.f - c2;
+  return alpha2 / (kPi * sqr(omc2 + alpha2 * c2));
+}
+DMT_DEV float ggx_lambda(float alpha2, float cos_N) {
+  return ggx_lambda_from(alpha2 * fmaxf(0.f, 1.f / sqr(cos_N)));
+}
+DMT_DEV float ggx_aniso_D(float ax, float ay, f3 lH) {
+  lH = lH / mk3(ax, ay, 1.f);
+  return kInvPi / ((ax * ay) * sqr(dot(lH, lH)));
+}
+DMT_DEV float ggx_aniso_lambda(float ax, float ay, f3 V) {
+  return ggx_lambda_from((sqr(ax * V.x) + sqr(ay * V.y)) / sqr(V.z));
+}
+constexpr float kThroughputEps = 1e-6f;
+
+DMT_DEV BsdfSample sample_ggx(Bsdf const& b, f3 wo, f3 ns, f3 ng, f2 u, float uc) {
+  BsdfSample s{};  // bsdf.cu:457-569
+  float const cos_NO = dot(ns, wo);
+  s.eta = 1.f;
+  float invEta = 1.f;
+  s.delta = fmaxf(b.ax, b.ay) < 1e-3f;
+  f3 H = ns, lH = mk3(0, 0, 0), lO = mk3(0, 0, 0);
+  if (!s.delta) {
+    f3 X, Y;
+    if (b.iso)
+      gram_schmidt(ns, X, Y);
+    else
+      orthonormal_tangent(ns, tangent_from_phi(ns, b.phi0), X, Y);
+    lO = mk3(dot(X, wo), dot(Y, wo), cos_NO);
+    lH = sample_ggx_vndf(lO, u, b.ax, b.ay);
+    H = lH.x * X + lH.y * Y + lH.z * ns;
+  }
+  float const cos_HO = dot(H, wo);
+  float cos_HI = 0.f;
+  f3 R, T;
+  microfacet_fresnel(b, cos_HO, cos_HI, R, T);
+  if (near_zero_pos(R, kThroughputEps) && near_zero_pos(T, kThroughputEps)) return s;
+  float const pdfReflect = fminf(fmaxf(average(R) / average(R + T), 0.f), 1.f);
+  s.refract = uc > pdfReflect;
+  if (s.refract) invEta = 1.f / b.eta;
+  // refractAngle (bsdf.cu:358-364) / mirror direction
+  s.wi = s.refract ? (invEta * dot(H, wo) + cos_HI) * H - invEta * wo : 2.f * cos_HO * H - wo;
+  if (dot(ng, s.wi) <= 0 && !s.refract) {
+    s.pdf = 0;
+    return s;
+  }
+  if (s.refract) {
+    s.f = T;
+    s.pdf = 1.f - pdfReflect;
+    s.delta = s.delta || (fabsf(s.eta - 1.f) < 1e-4f);  // eta is 1 here: refraction is "delta"
+  } else {
+    s.pdf = pdfReflect;  // the reference leaves f = 0 on the reflection lobe (bsdf.cu:526-534)
+  }
+  if (s.delta) {
+    s.pdf *= 1e6f;
+    s.f = s.f * 1e6f;
+  } else {
+    float D, lamI, lamO;
+    if (b.iso || s.refract) {
+      float const alpha2 = b.ax * b.ay;
+      D = ggx_D(alpha2, lH.z);
+      lamI = ggx_lambda(alpha2, dot(ns, s.wi));
+      lamO = ggx_lambda(alpha2, cos_NO);
+    } else {
+      f3 const lI = 2.f * cos_HO * lH - lO;
+      D = ggx_aniso_D(b.ax, b.ay, lH);
+      lamI = ggx_aniso_lambda(b.ax, b.ay, lI);
+      lamO = ggx_aniso_lambda(b.ax, b.ay, lO);
+    }
+    float const common =
+        D / cos_NO * (s.refract ? fabsf(cos_HO * cos_HI) / sqr(cos_HI + cos_HO * invEta) : 0.25f);
+    s.pdf *= common / (1.f + lamO);
+    s.f = s.f * (common / (1.f + lamO + lamI));
+  }
+  return s;
+}
+DMT_DEV f3 eval_ggx(Bsdf const& b, f3 wo, f3 wi, f3 ns, f3 ng, float& pdf) {  // bsdf.cu:571-667
+  bool const conductor = b.type == BS_GGX_COND;
+  bool const hasReflection = conductor ? true : luminance(b.c0) > kThroughputEps;
+  bool const hasTransmission = conductor ? false : luminance(b.c1) > kThroughputEps;
+  bool const isotropic = b.ax == b.ay;
+  float const cos_NO = dot(ns, wo);
+  float const cos_NI = dot(ns, wi);
+  float const cos_NgI = dot(ng, wi);
+  bool const isT = cos_NI < 0.f;
+  float const ior = isT ? b.eta : 1.f;
+  bool const effSpecular = fmaxf(b.ax, b.ay) < 1e-3f;
+  if (cos_NO <= 0.f || (cos_NgI < 0) != isT || effSpecular || (!hasReflection && cos_NgI > 0.f) ||
+      (!hasTransmission && cos_NgI < 0.f)) {
+    pdf = 0.f;
+    return mk3(0, 0, 0);
+  }
+  f3 H = isT ? (ior * wi + wo) : (wi + wo);
+  float const invLen_H = rsqrt_ieee(dot(H, H));
+  H = H * invLen_H;
+  float const cos_HO = dot(H, wo);
+  float unused = 0.f;
+  f3 R, T;
+  microfacet_fresnel(b, cos_HO, unused, R, T);
+  if (near_zero_pos(R, kThroughputEps) && near_zero_pos(T, kThroughputEps)) {
+    pdf = 0.f;
+    return mk3(0, 0, 0);
+  }
+  float const cos_NH = dot(ns, H);
+  float D, lamI, lamO;
+  if (isotropic || isT) {
+    float const alpha2 = b.ax * b.ay;
+    D = ggx_D(alpha2, cos_NH);
+    lamI = ggx_lambda(alpha2, cos_NI);
+    lamO = ggx_lambda(alpha2, cos_NO);
+  } else {
+    f3 X, Y;
+    orthonormal_tangent(ns, tangent_from_phi(ns, b.phi0), X, Y);
+    f3 const lH = mk3(dot(X, H), dot(Y, H), dot(ns, H));
+    f3 const lO = mk3(dot(X, wo), dot(Y, wo), cos_NO);
+    f3 const lI = mk3(dot(X, wi), dot(Y, wi), cos_NI);
+    D = ggx_aniso_D(b.ax, b.ay, lH);
+    lamI = ggx_aniso_lambda(b.ax, b.ay, lI);
+    lamO = ggx_aniso_lambda(b.ax, b.ay, lO);
+  }
+  float const common = D / cos_NO * (isT ? sqr(ior * invLen_H) * fabsf(cos_HO * dot(H, wi)) : 0.25f);
+  float const pdfReflect = average(R) / average(R + T);
+  float const lobePdf = isT ? 1.f - pdfReflect : pdfReflect;
+  pdf = lobePdf * common / (1.f + lamO);
+  return b.escale * (isT ? T : R) * common / (1.f + lamO + lamI);
+}
+
+DMT_DEV BsdfSample sample_bsdf(Bsdf const& b, f3 wo, f3 ns, f3 ng, f2 u, float uc) {
+  BsdfSample s{};  // bsdf.cu:851-880
+  if (dot(wo, ng) > 0.0f) {
+    if (dot(ns, ng) < 0.0f) ns = -ns;  // faceForward
+    if (b.type == BS_OREN || b.type == BS_LAMBERT) {
+      s.eta = 1.f;
+      s.wi = sample_cos_hemisphere(ns, u, s.pdf);
+      if (dot(ng, s.wi) > 0.f) {
+        s.f = b.type == BS_OREN ? oren_nayar_intensity(b, ns, wo, s.wi) : mk3(s.pdf, s.pdf, s.pdf);
+      } else {
+        s.pdf = 0;
+      }
+    } else {
+      s = sample_ggx(b, wo, ns, ng, u, uc);
+    }
+  }
+  return s;
+}
+DMT_DEV f3 eval_bsdf(Bsdf const& b, f3 wo, f3 wi, f3 ns, f3 ng, float& pdf) {  // bsdf.cu:882-907
+  pdf = 0;
+  if (b.type == BS_OREN) {
+    float const cos_NI = dot(ns, wi);
+    if (cos_NI > 0.f) {
+      pdf = cos_NI * kInvPi;
+      return oren_nayar_intensity(b, ns, wo, wi);
+    }
+    return mk3(0, 0, 0);
+  }
+  if (b.type == BS_LAMBERT) {
+    float const cos_NI = fmaxf(dot(ns, wi), 0.f);
+    pdf = cos_NI * kInvPi;
+    return mk3(pdf, pdf, pdf);
+  }
+  return eval_ggx(b, wo, wi, ns, ng, pdf);
+}
+
+// min(static_cast<int>(u * count), count - 1) with CUDA's min(int, unsigned) -> unsigned
+DMT_DEV uint32_t pick_index(float u, uint32_t count) {
+  uint32_t const a = uint32_t(int(u * float(count)));
+  uint32_t const b = count - 1u;
+  return a < b ? a : b;
+}
+
+}  // namespace dmt

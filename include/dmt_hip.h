@@ -1,0 +1,146 @@
+/* dmt_hip.h -- C ABI of the MI355X (gfx950) path-tracing hot path.
+ *
+ * Drop-in boundary for the reference's kernel-launch boundary (paths relative to
+ * /root/reference/examples/triangles/, T/ = that directory, CC/ = T/cuda-core/):
+ *
+ *   reference interface                                          replaced by
+ *   ------------------------------------------------------------ ---------------------------
+ *   cudaInitDevice/cudaSetDevice/cudaStreamCreate                dmt_ctx_create / _destroy
+ *     (T/megakernel/main.cu:135-136,264-265)
+ *   triSoupFromTriangles (CC/public/cuda-core/host_utils.cuh:163) dmt_upload_triangles
+ *   deviceBSDF           (host_utils.cuh:166)                    dmt_upload_bsdfs
+ *   deviceLights         (host_utils.cuh:167-169)                dmt_upload_lights
+ *   deviceCamera + allocateDeviceConstantMemory                  dmt_set_camera
+ *     (host_utils.cuh:170, T/megakernel/megakernel.cuh:18)
+ *   DeviceOutputBuffer::allocate/free (CC/public/cuda-core/types.cuh:175-193)
+ *                                                                dmt_set_camera / dmt_film_clear /
+ *                                                                dmt_film_bind
+ *   copyHaltonOwenToDeviceAlloc (host_utils.cuh:159)             (none: sampler state is per-lane
+ *                                                                registers, nothing to upload)
+ *   pathTraceMegakernel<<<...>>>(..., sampleOffset, ...)         dmt_render
+ *     (T/megakernel/megakernel.cuh:99-112, launch main.cu:141-155)
+ *   cudaStreamSynchronize (main.cu:169)                          dmt_sync
+ *   cudaMemcpyAsync D2H of mean / M2 (main.cu:202-205)           dmt_download_film
+ *   triangleIntersectKernel (T/tests/triangle_intersect.cu:146)  dmt_test_triangle_intersect
+ *
+ * Record layouts are byte-identical to the reference so its host packers interoperate:
+ *   BSDF  32 B  CC/public/cuda-core/bsdf.cuh:18-73
+ *   Light 32 B  CC/public/cuda-core/light.cuh:10-49
+ *   DeviceCamera 44 B  CC/public/cuda-core/types.cuh:101-109  (= dmt_camera below)
+ *   TriangleSoup: one float4 per axis per triangle {c0,c1,c2,pad} + uint32 matId
+ *                 (types.cuh:119-129)
+ *   film: two row-major float4 planes, mean.xyz (w = 0) and M2.xyz with the sample count N
+ *         in .w  (T/megakernel/megakernel.cuh:81-85, megakernel.cu:92-93)
+ *
+ * Ownership: the context owns all device memory; host pointers are borrowed for the call.
+ * Errors: every call returns DMT_OK (0) or a DMT_ERR_* code; the library never exits the
+ * process (the reference's CUDA_CHECK does, types.cuh:20-29).  A context is bound to one device
+ * and one stream and is not thread-safe; contexts are independent (one per GPU).
+ */
+#ifndef DMT_HIP_H
+#define DMT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dmt_ctx dmt_ctx;
+
+typedef struct dmt_camera {
+  float dir[3];
+  float pos[3];
+  int32_t width;
+  int32_t height;
+  int32_t spp; /* kept for layout parity; dmt_render's spp argument is what is rendered */
+  float focal_length; /* mm */
+  float sensor_size;  /* mm */
+} dmt_camera;
+
+enum {
+  DMT_OK = 0,
+  DMT_ERR_INVALID = 1,   /* bad argument */
+  DMT_ERR_HIP = 2,       /* a HIP runtime call failed; see dmt_last_error */
+  DMT_ERR_STATE = 3,     /* call sequence error (e.g. render before upload) */
+  DMT_ERR_NO_DEVICE = 4, /* no usable GPU */
+};
+
+enum {
+  DMT_ACCEL_BRUTE_FORCE = 0, /* the reference's loop over all triangles */
+  DMT_ACCEL_BVH = 1,         /* same closest hit (lowest index on ties), BVH traversal */
+};
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int dmt_ctx_create(int device_ordinal, dmt_ctx** out);
+int dmt_ctx_destroy(dmt_ctx* ctx);
+/* last error text of the context; ctx == NULL returns the last dmt_ctx_create failure */
+const char* dmt_last_error(const dmt_ctx* ctx);
+
+/* ---- scene upload ------------------------------------------------------------------------ */
+int dmt_upload_triangles(dmt_ctx* ctx, const float* xs, const float* ys, const float* zs,
+                         const uint32_t* mat_id, size_t count);
+int dmt_upload_bsdfs(dmt_ctx* ctx, const void* bsdf32, uint32_t count);
+int dmt_upload_lights(dmt_ctx* ctx, const void* lights32, uint32_t count, const void* infinite32,
+                      uint32_t infinite_count);
+/* (re)computes camera transforms and sampler parameters; (re)allocates and zeroes the film when
+ * the resolution changes */
+int dmt_set_camera(dmt_ctx* ctx, const dmt_camera* cam);
+/* depth cap of the bounce loop; the reference hard-codes 32 (megakernel.cu:154) */
+int dmt_set_limits(dmt_ctx* ctx, int max_depth);
+int dmt_set_accel(dmt_ctx* ctx, int mode);
+/* tile partition for multi-GPU rendering: this context renders only the 8x8-pixel tiles whose
+ * index (row-major over the tile grid) is congruent to `rank` modulo `world`.  Default 0 of 1. */
+int dmt_set_partition(dmt_ctx* ctx, int rank, int world);
+/* borrow an external hipStream_t (e.g. the caller's); NULL restores the context's own stream */
+int dmt_set_stream(dmt_ctx* ctx, void* hip_stream);
+
+/* ---- film ---------------------------------------------------------------------------------- */
+int dmt_film_clear(dmt_ctx* ctx);
+/* use caller-owned device buffers (width*height float4 each) instead of the context's own */
+int dmt_film_bind(dmt_ctx* ctx, void* d_mean, void* d_m2);
+int dmt_film_device_ptrs(dmt_ctx* ctx, void** d_mean, void** d_m2);
+int dmt_download_film(dmt_ctx* ctx, float* mean4, float* m24);
+
+/* ---- render -------------------------------------------------------------------------------- */
+/* Enqueue one pass: samples [sample_offset, sample_offset + spp) of every owned pixel in
+ * [x0,x1) x [y0,y1) are traced and folded into the film (Welford, in sample order).
+ * Asynchronous on the context's stream. */
+int dmt_render(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1);
+int dmt_sync(dmt_ctx* ctx);
+/* HIP-event time of the megakernel launches since the last reset (synchronises the stream):
+ * total milliseconds and launch count. */
+int dmt_kernel_time(dmt_ctx* ctx, double* total_ms, uint64_t* launches, int reset);
+/* compile-time facts of the loaded code object: vgprs, sgprs, LDS bytes, max resident waves/CU
+ * as reported by the runtime for the megakernel; CU count of the device */
+int dmt_kernel_info(dmt_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* blocks_per_cu,
+                    int* cu_count);
+
+/* ---- device unit-test entry points (GPU twins of the reference's T/tests kernels) ---------- */
+int dmt_test_triangle_intersect(dmt_ctx* ctx, const float* xs, const float* ys, const float* zs,
+                                size_t count, const float* o3, const float* d3, int32_t* hit,
+                                float* t, float* pos3, float* nrm3, float* err3);
+int dmt_test_sampler(dmt_ctx* ctx, int width, int height, int n, const int32_t* pxs,
+                     const int32_t* pys, const int32_t* ss, int ndims, int32_t* halton_index,
+                     float* pixel2d, float* dims);
+int dmt_test_camera_rays(dmt_ctx* ctx, int n, const int32_t* pxs, const int32_t* pys,
+                         const int32_t* ss, float* o3, float* d3);
+int dmt_test_bsdf(dmt_ctx* ctx, const void* bsdf32, int n, const float* ns3, const float* wo3,
+                  const float* u2, const float* uc, const float* wi_eval3, float* prepared12,
+                  float* sample10, float* eval4);
+int dmt_test_light(dmt_ctx* ctx, const void* light32, int n, const float* pos3, const float* nrm3,
+                   const float* u2, const int32_t* had_transmission, float* out14);
+int dmt_test_half(dmt_ctx* ctx, int n, const float* f_in, uint16_t* h_out, const uint16_t* h_in,
+                  float* f_out);
+/* radiance of individual (pixel, sample) paths of the uploaded scene */
+int dmt_test_trace_samples(dmt_ctx* ctx, int n, const int32_t* pxs, const int32_t* pys,
+                           const int32_t* ss, float* L3);
+/* closest hit (triangle index or -1, t) of rays against the uploaded scene, current accel mode */
+int dmt_test_closest_hit(dmt_ctx* ctx, int nrays, const float* o3, const float* d3,
+                         int32_t* tri_index, float* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMT_HIP_H */
