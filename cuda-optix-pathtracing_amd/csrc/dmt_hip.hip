@@ -1,0 +1,1066 @@
+// dmt_hip.hip -- gfx950 megakernel + C ABI (include/dmt_hip.h).
+//
+// Kernel design (MI355X-first, not a translation of T/megakernel/megakernel.cu):
+//   * work item = one 8x8-pixel tile x all samples of the pass; waves pull items from a global
+//     atomic counter (persistent threads + work stealing) instead of a static grid-stride loop;
+//   * one lane = one pixel; when a lane's path ends it folds the radiance into its Welford
+//     registers and immediately regenerates the next sample of the same pixel, so a wave never
+//     waits for its longest path (the reference reconverges the warp after every sample);
+//   * everything the reference does between two ray casts (BSDF prepare, light sample, NEE
+//     weight, BSDF sample, Russian roulette) is evaluated BEFORE the shadow ray is traced, so the
+//     shadow ray of bounce k and the closest-hit ray of bounce k+1 go through ONE pass over the
+//     triangle array: two independent Moeller-Trumbore chains per lane (ILP) and each triangle is
+//     fetched once.  Radiance is still accumulated in the reference's order.
+//   * brute-force mode keeps the reference's "loop over every triangle" semantics: the loop
+//     index is wave-uniform, so triangle records arrive through scalar loads (s_load_dwordx4)
+//     and live in SGPRs -- no LDS or VGPR traffic in the hot loop.
+//   * film state (mean, M2, N) stays in registers for the whole item; one 32-byte read and one
+//     32-byte write per pixel per pass.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dmt_hip.h"
+#include "pt_device.hpp"
+
+using namespace dmt;
+
+namespace {
+
+struct RenderParams {
+  SceneView scene;
+  CameraXf cam;
+  SamplerParams sp;
+  float4* __restrict__ mean;
+  float4* __restrict__ m2;
+  uint32_t* __restrict__ counter;
+  int width, height;
+  int x0, y0, x1, y1;     // pixel region
+  int tx0, ty0, rtx;      // tile grid of the region: origin (in tiles) and tiles per row
+  uint32_t numItems;      // owned tiles
+  int rank, world;
+  uint32_t sampleOffset, spp;
+  int maxDepth;
+};
+
+struct PathState {
+  Ray ray;
+  f3 beta, L;
+  int depth;
+  bool lastT;
+  bool traceClosest;
+  bool hasShadow;
+  Ray sray;
+  float smax;
+  f3 C;
+  Sampler rng;
+};
+
+DMT_DEV void path_begin(PathState& st, CameraXf const& cam, SamplerParams const& sp, int px, int py,
+                        int32_t pixBase, uint32_t s) {
+  int32_t const hidx = pixBase + int32_t(s) * (sp.scale0 * sp.scale1);
+  st.rng.start(uint32_t(hidx));
+  st.ray = camera_ray(cam, sp, px, py, hidx);
+  st.beta = mk3(1, 1, 1);
+  st.L = mk3(0, 0, 0);
+  st.depth = 0;
+  st.lastT = false;
+  st.traceClosest = true;
+  st.hasShadow = false;
+}
+
+// Everything between two ray casts (T/megakernel/megakernel.cu:135-295).  Returns true when the
+// path ends.  May leave a pending shadow ray (st.hasShadow) whose contribution st.C is added by
+// the caller once visibility is known.
+DMT_DEV bool path_shade(SceneView const& sc, int maxDepth, PathState& st, int bestTri, float bu,
+                        float bv) {
+  if (bestTri < 0) {  // miss: constant environment, no MIS (megakernel.cu:135-151)
+    if (sc.infLightCount > 0) {
+      uint32_t const li = pick_index(st.rng.get1D(), sc.infLightCount);
+      Rec32 const light = sc.infLights[li];
+      float const pmf = 1.f / float(sc.infLightCount);
+      if (light_type(light) == LT_ENV) st.L = st.L + st.beta * light_intensity(light) / pmf;
+    }
+    return true;
+  }
+  if (st.depth >= maxDepth) return true;  // :154-158
+
+  Hit const hit = hit_finish(sc.post[bestTri], bu, bv, st.ray.d);
+  f3 const wo = -st.ray.d;
+  Bsdf const b = bsdf_prepare(sc.bsdfs[hit.matId], hit.normal, wo);  // :165-166
+
+  // next-event estimation (:170-241)
+  float const uLight = st.rng.get1D();
+  f2 const uLight2 = st.rng.get2D();
+  if (sc.lightCount > 0) {
+    uint32_t const li = pick_index(uLight, sc.lightCount);
+    Rec32 const light = sc.lights[li];
+    float const pmf = 1.f / float(sc.lightCount);
+    LightSample const ls = sample_light(light, hit.pos, uLight2, st.lastT, hit.normal);
+    if (ls.valid()) {
+      float bsdfPdf = 0.f;
+      f3 const f = eval_bsdf(b, wo, ls.direction, hit.normal, hit.normal, bsdfPdf) * b.weight;
+      if (!is_zero(f)) {
+        f3 const Le = eval_light(light, ls);
+        if (ls.delta) {
+          st.C = st.beta * Le * f / pmf;
+        } else {  // power heuristic, no division by the light pdf (:233-238)
+          float const w = sqr(pmf * ls.pdf) / sqr(pmf * ls.pdf + bsdfPdf);
+          st.C = Le * f * st.beta * w;
+        }
+        st.sray.o = offset_ray_origin(hit.pos, hit.error, hit.normal, ls.direction);
+        st.sray.d = ls.direction;
+        st.smax = ls.distance;
+        st.hasShadow = true;
+      }
+      // f == 0: the reference traces the shadow ray and then adds nothing; not traced here
+    }
+  }
+
+  // bounce (:247-295); get2D before get1D = left-to-right argument evaluation
+  f2 const u2 = st.rng.get2D();
+  float const uc = st.rng.get1D();
+  BsdfSample const bs = sample_bsdf(b, wo, hit.normal, hit.normal, u2, uc);
+  if (!bs.valid()) return true;
+  st.lastT = bs.refract;
+  st.ray.o = offset_ray_origin(hit.pos, hit.error, hit.normal, bs.wi);
+  st.ray.d = bs.wi;
+  st.beta = st.beta * (bs.f * fabsf(dot(bs.wi, hit.normal)) / bs.pdf);
+  float const rrBeta = max3(st.beta * bs.eta);
+  if (rrBeta < 1 && st.depth > 1) {
+    float const q = fmaxf(0.f, 1.f - rrBeta);
+    if (st.rng.get1D() < q) return true;
+    st.beta = st.beta / (1 - q);
+  }
+  ++st.depth;
+  return false;
+}
+
+// One pass over the triangle array for up to two rays per lane: closest hit for st.ray and
+// any-hit for st.sray.  Brute force; loop index is wave-uniform -> scalar loads.
+DMT_DEV void trace_pair_brute(SceneView const& sc, PathState const& st, bool doC, bool doS,
+                              int& bestTri, float& bu, float& bv, bool& occluded) {
+  float bt = kInf;
+  bestTri = -1;
+  bu = 0.f, bv = 0.f;
+  occluded = false;
+  for (uint32_t i = 0; i < sc.triCount; ++i) {
+    TriIsect const T = sc.tris[i];
+    MTResult const r1 = mt_test(T, st.ray);
+    MTResult const r2 = mt_test(T, st.sray);
+    if (doC && r1.valid && r1.t < bt) {  // strict <: lowest index wins ties (megakernel.cu:126)
+      bt = r1.t;
+      bestTri = int(i);
+      bu = r1.u;
+      bv = r1.v;
+    }
+    if (doS && r2.valid && r2.t < st.smax) occluded = true;  // :210-211
+  }
+}
+
+// Advance one lane by one "ray pass".  Returns true when the sample is complete (st.L final).
+DMT_DEV bool path_advance(SceneView const& sc, int maxDepth, PathState& st, bool alive) {
+  bool const doC = alive && st.traceClosest;
+  bool const doS = alive && st.hasShadow;
+  int bestTri;
+  float bu, bv;
+  bool occluded;
+  trace_pair_brute(sc, st, doC, doS, bestTri, bu, bv, occluded);
+  if (doS) {
+    if (!occluded) st.L = st.L + st.C;
+    st.hasShadow = false;
+  }
+  bool ended = false;
+  if (doC) {
+    ended = path_shade(sc, maxDepth, st, bestTri, bu, bv);
+    if (ended) st.traceClosest = false;
+  } else if (alive) {
+    ended = true;  // was only waiting for its last shadow ray
+  }
+  return alive && ended && !st.hasShadow;
+}
+
+__global__ void __launch_bounds__(256) k_megakernel(RenderParams P) {
+  int const lane = int(threadIdx.x) & 63;
+  for (;;) {
+    uint32_t item = 0;
+    if (lane == 0) item = atomicAdd(P.counter, 1u);
+    item = uint32_t(__builtin_amdgcn_readfirstlane(int(item)));
+    if (item >= P.numItems) break;
+    uint32_t const j = uint32_t(P.rank) + item * uint32_t(P.world);
+    int const tx = P.tx0 + int(j % uint32_t(P.rtx));
+    int const ty = P.ty0 + int(j / uint32_t(P.rtx));
+    int const px = tx * 8 + (lane & 7);
+    int const py = ty * 8 + (lane >> 3);
+    bool const inside = px >= P.x0 && px < P.x1 && py >= P.y0 && py < P.y1;
+    size_t const pidx = size_t(px) + size_t(py) * size_t(P.width);
+
+    f3 mean = mk3(0, 0, 0), M2 = mk3(0, 0, 0);
+    float N = 0.f;
+    int32_t pixBase = 0;
+    if (inside) {  // SMEMLayout::startSample, T/megakernel/megakernel.cuh:45-57
+      float4 const m = P.mean[pidx];
+      float4 const v = P.m2[pidx];
+      mean = mk3(m.x, m.y, m.z);
+      M2 = mk3(v.x, v.y, v.z);
+      N = v.w;
+      pixBase = halton_pixel_base(P.sp, px, py);
+    }
+    uint32_t s = P.sampleOffset;
+    uint32_t const sEnd = P.sampleOffset + P.spp;
+    PathState st{};
+    bool needNew = true;
+    bool alive = inside;
+    for (;;) {
+      if (alive && needNew) {
+        if (s < sEnd) {
+          path_begin(st, P.cam, P.sp, px, py, pixBase, s);
+          needNew = false;
+        } else {
+          alive = false;
+        }
+      }
+      if (!__any(alive)) break;
+      if (path_advance(P.scene, P.maxDepth, st, alive)) {
+        // Welford update, megakernel.cuh:59-79
+        N += 1.0f;
+        f3 const delta = st.L - mean;
+        mean = mean + delta / N;
+        f3 const delta2 = st.L - mean;
+        M2 = M2 + delta * delta2;
+        ++s;
+        needNew = true;
+      }
+    }
+    if (inside) {  // endSample, megakernel.cuh:81-85
+      P.mean[pidx] = make_float4(mean.x, mean.y, mean.z, 0.f);
+      P.m2[pidx] = make_float4(M2.x, M2.y, M2.z, N);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// device unit-test kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void k_test_trace(SceneView sc, CameraXf cam, SamplerParams sp, int maxDepth, int n,
+                             int32_t const* pxs, int32_t const* pys, int32_t const* ss, float* L3) {
+  int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
+  bool alive = i < n;
+  PathState st{};
+  if (alive) path_begin(st, cam, sp, pxs[i], pys[i], halton_pixel_base(sp, pxs[i], pys[i]), uint32_t(ss[i]));
+  for (;;) {
+    if (!__any(alive)) break;
+    if (path_advance(sc, maxDepth, st, alive)) {
+      L3[3 * i] = st.L.x, L3[3 * i + 1] = st.L.y, L3[3 * i + 2] = st.L.z;
+      alive = false;
+    }
+  }
+}
+
+__global__ void k_test_tri(float const* xs, float const* ys, float const* zs, uint32_t n, f3 o, f3 d,
+                           int32_t* hit, float* t, float* pos3, float* nrm3, float* err3) {
+  uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  f3 const p0 = mk3(xs[4 * i], ys[4 * i], zs[4 * i]);
+  f3 const p1 = mk3(xs[4 * i + 1], ys[4 * i + 1], zs[4 * i + 1]);
+  f3 const p2 = mk3(xs[4 * i + 2], ys[4 * i + 2], zs[4 * i + 2]);
+  f3 const e0 = mk3(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z);
+  f3 const e1 = mk3(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z);
+  Ray const ray{o, d};
+  MTResult const r = mt_test(p0, e0, e1, ray);
+  hit[i] = r.valid ? 1 : 0;
+  float const inf = kInf;
+  t[i] = r.valid ? r.t : inf;
+  f3 pos = mk3(0, 0, 0), nrm = mk3(0, 0, 0), err = mk3(0, 0, 0);
+  if (r.valid) {
+    TriPost P;
+    P.p0x = p0.x, P.p0y = p0.y, P.p0z = p0.z, P.p1x = p1.x, P.p1y = p1.y, P.p1z = p1.z;
+    P.p2x = p2.x, P.p2y = p2.y, P.p2z = p2.z;
+    f3 const nn = normalize(cross(e1, e0));
+    P.nx = nn.x, P.ny = nn.y, P.nz = nn.z;
+    P.matId = 0;
+    Hit const h = hit_finish(P, r.u, r.v, mk3(0, 0, 0));  // zero direction: normal not flipped
+    pos = h.pos, nrm = h.normal, err = h.error;
+  }
+  pos3[3 * i] = pos.x, pos3[3 * i + 1] = pos.y, pos3[3 * i + 2] = pos.z;
+  nrm3[3 * i] = nrm.x, nrm3[3 * i + 1] = nrm.y, nrm3[3 * i + 2] = nrm.z;
+  err3[3 * i] = err.x, err3[3 * i + 1] = err.y, err3[3 * i + 2] = err.z;
+}
+
+__global__ void k_test_sampler(SamplerParams sp, int n, int32_t const* pxs, int32_t const* pys,
+                               int32_t const* ss, int ndims, int32_t* hidx, float* pix2, float* dims) {
+  int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  int32_t const h = halton_pixel_base(sp, pxs[i], pys[i]) + ss[i] * (sp.scale0 * sp.scale1);
+  hidx[i] = h;
+  f2 const p = pixel2d(sp, h);
+  pix2[2 * i] = p.x, pix2[2 * i + 1] = p.y;
+  Sampler r;
+  r.start(uint32_t(h));
+  for (int d = 0; d < ndims; ++d) dims[size_t(i) * ndims + d] = r.get1D();
+}
+
+__global__ void k_test_camera(CameraXf cam, SamplerParams sp, int n, int32_t const* pxs,
+                              int32_t const* pys, int32_t const* ss, float* o3, float* d3) {
+  int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  int32_t const h = halton_pixel_base(sp, pxs[i], pys[i]) + ss[i] * (sp.scale0 * sp.scale1);
+  Ray const r = camera_ray(cam, sp, pxs[i], pys[i], h);
+  o3[3 * i] = r.o.x, o3[3 * i + 1] = r.o.y, o3[3 * i + 2] = r.o.z;
+  d3[3 * i] = r.d.x, d3[3 * i + 1] = r.d.y, d3[3 * i + 2] = r.d.z;
+}
+
+__global__ void k_test_bsdf(Rec32 rec, int n, float const* ns3, float const* wo3, float const* u2,
+                            float const* uc, float const* wi3, float* prep12, float* samp10,
+                            float* eval4) {
+  int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  f3 const ns = mk3(ns3[3 * i], ns3[3 * i + 1], ns3[3 * i + 2]);
+  f3 const wo = mk3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
+  Bsdf const b = bsdf_prepare(rec, ns, wo);
+  float* p = prep12 + 12 * size_t(i);
+  p[0] = b.weight.x, p[1] = b.weight.y, p[2] = b.weight.z;
+  p[3] = b.ms.x, p[4] = b.ms.y, p[5] = b.ms.z;
+  p[6] = b.escale, p[7] = float(b.type), p[8] = b.ax, p[9] = b.ay, p[10] = b.phi0, p[11] = b.eta;
+  BsdfSample const s = sample_bsdf(b, wo, ns, ns, mk2(u2[2 * i], u2[2 * i + 1]), uc[i]);
+  float* o = samp10 + 10 * size_t(i);
+  o[0] = s.wi.x, o[1] = s.wi.y, o[2] = s.wi.z, o[3] = s.f.x, o[4] = s.f.y, o[5] = s.f.z;
+  o[6] = s.pdf, o[7] = s.eta, o[8] = s.delta ? 1.f : 0.f, o[9] = s.refract ? 1.f : 0.f;
+  float pdf = 0.f;
+  f3 const f = eval_bsdf(b, wo, mk3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), ns, ns, pdf) * b.weight;
+  float* e = eval4 + 4 * size_t(i);
+  e[0] = f.x, e[1] = f.y, e[2] = f.z, e[3] = pdf;
+}
+
+__global__ void k_test_light(Rec32 rec, int n, float const* pos3, float const* nrm3, float const* u2,
+                             int32_t const* hadT, float* out14) {
+  int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  LightSample const s = sample_light(rec, mk3(pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2]),
+                                     mk2(u2[2 * i], u2[2 * i + 1]), hadT[i] != 0,
+                                     mk3(nrm3[3 * i], nrm3[3 * i + 1], nrm3[3 * i + 2]));
+  f3 const Le = eval_light(rec, s);
+  float* o = out14 + 14 * size_t(i);
+  o[0] = s.pLight.x, o[1] = s.pLight.y, o[2] = s.pLight.z;
+  o[3] = s.direction.x, o[4] = s.direction.y, o[5] = s.direction.z;
+  o[6] = s.pdf, o[7] = float(s.delta), o[8] = s.distance, o[9] = s.factor;
+  o[10] = Le.x, o[11] = Le.y, o[12] = Le.z, o[13] = s.valid() ? 1.f : 0.f;
+}
+
+__global__ void k_test_half(int n, float const* fin, uint16_t* hout, uint16_t const* hin, float* fout) {
+  int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  if (fin && hout) hout[i] = uint16_t(f2h(fin[i]));
+  if (hin && fout) fout[i] = h2f(hin[i]);
+}
+
+__global__ void k_test_closest(SceneView sc, int n, float const* o3, float const* d3, int32_t* tri,
+                               float* tOut) {
+  int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
+  bool const alive = i < n;
+  PathState st{};
+  if (alive) {
+    st.ray.o = mk3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
+    st.ray.d = mk3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+  }
+  float bt = kInf;
+  int best = -1;
+  for (uint32_t k = 0; k < sc.triCount; ++k) {
+    MTResult const r = mt_test(sc.tris[k], st.ray);
+    if (alive && r.valid && r.t < bt) bt = r.t, best = int(k);
+  }
+  if (alive) tri[i] = best, tOut[i] = bt;
+}
+
+}  // namespace
+
+// =============================================================================================
+// host side of the C ABI
+// =============================================================================================
+struct dmt_ctx {
+  int device = 0;
+  hipStream_t ownStream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // scene
+  TriIsect* d_tris = nullptr;
+  TriPost* d_post = nullptr;
+  Rec32* d_bsdfs = nullptr;
+  Rec32* d_lights = nullptr;
+  Rec32* d_inf = nullptr;
+  uint32_t triCount = 0, bsdfCount = 0, lightCount = 0, infCount = 0;
+  uint32_t maxMatId = 0;
+  bool haveTris = false, haveBsdfs = false, haveLights = false, haveCamera = false;
+  // camera
+  dmt_camera cam{};
+  CameraXf xf{};
+  SamplerParams sp{};
+  // film
+  float4* d_mean = nullptr;
+  float4* d_m2 = nullptr;
+  bool ownFilm = false;
+  int filmW = 0, filmH = 0;
+  uint32_t* d_counter = nullptr;
+  int maxDepth = 32;
+  int accel = DMT_ACCEL_BRUTE_FORCE;
+  int rank = 0, world = 1;
+  // launch geometry
+  int cuCount = 0;
+  int blocksPerCU = 0;
+  // timing
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t eventsUsed = 0;
+  double accumMs = 0.0;
+  uint64_t accumLaunches = 0;
+};
+
+namespace {
+
+std::string g_createError;
+
+#define HIP_TRY(ctx, call)                                                                 \
+  do {                                                                                     \
+    hipError_t const e__ = (call);                                                         \
+    if (e__ != hipSuccess) {                                                               \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorName(e__) + " - " +              \
+                   hipGetErrorString(e__);                                                 \
+      return DMT_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+int fail(dmt_ctx* ctx, int code, char const* msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+// ---- host math for the one-off camera / sampler setup (IEEE fp32, same expressions as the
+// reference host code: CC/private/extra_math.cu:43-90, CC/private/common_math.cu:16-78,
+// CC/private/rng.cu:21-46,182-208)
+struct H3 {
+  float x, y, z;
+};
+H3 hcross(H3 a, H3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+H3 hnormalize(H3 a) {
+  float const inv = 1.0f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+  return {a.x * inv, a.y * inv, a.z * inv};
+}
+void worldFromCamera(float const dir[3], float const pos[3], float m[16]) {
+  H3 const fwd = hnormalize({dir[0], dir[1], dir[2]});
+  H3 const right = hnormalize(hcross(fwd, {0, 0, 1}));
+  H3 const up = hcross(right, fwd);
+  m[0] = right.x, m[4] = up.x, m[8] = fwd.x, m[12] = pos[0];
+  m[1] = right.y, m[5] = up.y, m[9] = fwd.y, m[13] = pos[1];
+  m[2] = right.z, m[6] = up.z, m[10] = fwd.z, m[14] = pos[2];
+  m[3] = 0.f, m[7] = 0.f, m[11] = 0.f, m[15] = 1.f;
+}
+void cameraFromRaster(float focal_mm, float sensorH_mm, uint32_t xRes, uint32_t yRes, float m[16]) {
+  float const sensorW_mm = sensorH_mm * float(xRes) / float(yRes);
+  float const MM = 0.001f;
+  float const focal = focal_mm * MM, sh = sensorH_mm * MM, sw = sensorW_mm * MM;
+  float const psx = sw / float(xRes), psy = sh / float(yRes);
+  float const tx = -0.5f * sw + 0.5f * psx;
+  float const ty = 0.5f * sh - 0.5f * psy;
+  for (int i = 0; i < 16; ++i) m[i] = 0.f;
+  m[0] = psx, m[5] = -psy, m[10] = 1.f, m[12] = tx, m[13] = ty, m[14] = focal, m[15] = 1.f;
+}
+int64_t multInverse(int64_t a, int64_t n) {
+  int64_t t = 0, nt = 1, r = n, nr = a;
+  while (nr != 0) {
+    int64_t const q = r / nr;
+    int64_t tmp = t - q * nt;
+    t = nt, nt = tmp;
+    tmp = r - q * nr;
+    r = nr, nr = tmp;
+  }
+  return t < 0 ? t + n : t;
+}
+SamplerParams computeSamplerParams(int width, int height) {
+  SamplerParams p{};
+  int const res[2] = {width, height};
+  int32_t scale[2], ex[2];
+  int const base[2] = {2, 3};
+  for (int i = 0; i < 2; ++i) {
+    scale[i] = 1, ex[i] = 0;
+    int const lim = res[i] < 128 ? res[i] : 128;
+    while (scale[i] < lim) scale[i] *= base[i], ++ex[i];
+  }
+  p.scale0 = scale[0], p.scale1 = scale[1], p.exp0 = ex[0], p.exp1 = ex[1];
+  p.inv0 = int32_t(multInverse(scale[1], scale[0]));
+  p.inv1 = int32_t(multInverse(scale[0], scale[1]));
+  return p;
+}
+
+SceneView sceneView(dmt_ctx const* c) {
+  SceneView s;
+  s.tris = c->d_tris, s.post = c->d_post, s.bsdfs = c->d_bsdfs, s.lights = c->d_lights;
+  s.infLights = c->d_inf;
+  s.triCount = c->triCount, s.bsdfCount = c->bsdfCount, s.lightCount = c->lightCount;
+  s.infLightCount = c->infCount;
+  return s;
+}
+
+template <class T>
+int devAlloc(dmt_ctx* ctx, T** p, size_t n) {
+  if (*p) {
+    (void)hipFree(*p);
+    *p = nullptr;
+  }
+  if (n == 0) n = 1;
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return DMT_OK;
+}
+
+// scratch buffers for the test entry points
+struct Scratch {
+  dmt_ctx* ctx;
+  std::vector<void*> ptrs;
+  explicit Scratch(dmt_ctx* c) : ctx(c) {}
+  ~Scratch() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <class T>
+  T* up(T const* host, size_t n) {  // upload (or allocate when host == nullptr)
+    void* d = nullptr;
+    if (hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    ptrs.push_back(d);
+    if (host && n && hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return static_cast<T*>(d);
+  }
+};
+#define SCRATCH_CHECK(ctx, p) \
+  if (!(p)) return fail(ctx, DMT_ERR_HIP, "scratch allocation / upload failed")
+
+int finishTest(dmt_ctx* ctx) {
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DMT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
+  if (!out) return DMT_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    g_createError = "no HIP device available (the HIP path has no CPU fallback)";
+    return DMT_ERR_NO_DEVICE;
+  }
+  if (device_ordinal < 0 || device_ordinal >= count) {
+    g_createError = "device ordinal out of range";
+    return DMT_ERR_INVALID;
+  }
+  dmt_ctx* ctx = new (std::nothrow) dmt_ctx();
+  if (!ctx) return DMT_ERR_INVALID;
+  ctx->device = device_ordinal;
+  hipError_t e = hipSetDevice(device_ordinal);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking);
+  hipDeviceProp_t prop{};
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_ordinal);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counter), sizeof(uint32_t));
+  int bpc = 0;
+  if (e == hipSuccess)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, reinterpret_cast<void const*>(k_megakernel), 256, 0);
+  if (e != hipSuccess) {
+    g_createError = std::string("dmt_ctx_create: ") + hipGetErrorString(e);
+    if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
+    delete ctx;
+    return DMT_ERR_HIP;
+  }
+  ctx->stream = ctx->ownStream;
+  ctx->cuCount = prop.multiProcessorCount;
+  ctx->blocksPerCU = bpc > 0 ? bpc : 1;
+  *out = ctx;
+  return DMT_OK;
+}
+
+int dmt_ctx_destroy(dmt_ctx* ctx) {
+  if (!ctx) return DMT_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& ev : ctx->events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  (void)hipFree(ctx->d_tris);
+  (void)hipFree(ctx->d_post);
+  (void)hipFree(ctx->d_bsdfs);
+  (void)hipFree(ctx->d_lights);
+  (void)hipFree(ctx->d_inf);
+  (void)hipFree(ctx->d_counter);
+  if (ctx->ownFilm) {
+    (void)hipFree(ctx->d_mean);
+    (void)hipFree(ctx->d_m2);
+  }
+  if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
+  delete ctx;
+  return DMT_OK;
+}
+
+const char* dmt_last_error(const dmt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
+
+int dmt_upload_triangles(dmt_ctx* ctx, const float* xs, const float* ys, const float* zs,
+                         const uint32_t* mat_id, size_t count) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if ((count && (!xs || !ys || !zs || !mat_id)) || count > 0x7FFFFFFFu)
+    return fail(ctx, DMT_ERR_INVALID, "dmt_upload_triangles: null array or count out of range");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::vector<TriIsect> a(count);
+  std::vector<TriPost> b(count);
+  uint32_t maxMat = 0;
+  for (size_t i = 0; i < count; ++i) {
+    if (mat_id[i] > maxMat) maxMat = mat_id[i];
+    H3 const p0{xs[4 * i], ys[4 * i], zs[4 * i]};
+    H3 const p1{xs[4 * i + 1], ys[4 * i + 1], zs[4 * i + 1]};
+    H3 const p2{xs[4 * i + 2], ys[4 * i + 2], zs[4 * i + 2]};
+    H3 const e0{p1.x - p0.x, p1.y - p0.y, p1.z - p0.z};
+    H3 const e1{p2.x - p0.x, p2.y - p0.y, p2.z - p0.z};
+    H3 const n = hnormalize(hcross(e1, e0));
+    TriIsect& t = a[i];
+    t.p0x = p0.x, t.p0y = p0.y, t.p0z = p0.z;
+    t.e0x = e0.x, t.e0y = e0.y, t.e0z = e0.z;
+    t.e1x = e1.x, t.e1y = e1.y, t.e1z = e1.z;
+    t.matId = mat_id[i], t.pad0 = 0, t.pad1 = 0;
+    TriPost& q = b[i];
+    q.p0x = p0.x, q.p0y = p0.y, q.p0z = p0.z;
+    q.p1x = p1.x, q.p1y = p1.y, q.p1z = p1.z;
+    q.p2x = p2.x, q.p2y = p2.y, q.p2z = p2.z;
+    q.nx = n.x, q.ny = n.y, q.nz = n.z;
+    q.matId = mat_id[i], q.pad0 = q.pad1 = q.pad2 = 0;
+  }
+  int rc = devAlloc(ctx, &ctx->d_tris, count);
+  if (rc) return rc;
+  rc = devAlloc(ctx, &ctx->d_post, count);
+  if (rc) return rc;
+  if (count) {
+    HIP_TRY(ctx, hipMemcpy(ctx->d_tris, a.data(), count * sizeof(TriIsect), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_post, b.data(), count * sizeof(TriPost), hipMemcpyHostToDevice));
+  }
+  ctx->triCount = uint32_t(count);
+  ctx->maxMatId = maxMat;
+  ctx->haveTris = true;
+  return DMT_OK;
+}
+
+int dmt_upload_bsdfs(dmt_ctx* ctx, const void* bsdf32, uint32_t count) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if (count && !bsdf32) return fail(ctx, DMT_ERR_INVALID, "dmt_upload_bsdfs: null array");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = devAlloc(ctx, &ctx->d_bsdfs, count);
+  if (rc) return rc;
+  if (count) HIP_TRY(ctx, hipMemcpy(ctx->d_bsdfs, bsdf32, size_t(count) * 32, hipMemcpyHostToDevice));
+  ctx->bsdfCount = count;
+  ctx->haveBsdfs = true;
+  return DMT_OK;
+}
+
+int dmt_upload_lights(dmt_ctx* ctx, const void* lights32, uint32_t count, const void* infinite32,
+                      uint32_t infinite_count) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if ((count && !lights32) || (infinite_count && !infinite32))
+    return fail(ctx, DMT_ERR_INVALID, "dmt_upload_lights: null array");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = devAlloc(ctx, &ctx->d_lights, count);
+  if (rc) return rc;
+  rc = devAlloc(ctx, &ctx->d_inf, infinite_count);
+  if (rc) return rc;
+  if (count) HIP_TRY(ctx, hipMemcpy(ctx->d_lights, lights32, size_t(count) * 32, hipMemcpyHostToDevice));
+  if (infinite_count)
+    HIP_TRY(ctx, hipMemcpy(ctx->d_inf, infinite32, size_t(infinite_count) * 32, hipMemcpyHostToDevice));
+  ctx->lightCount = count;
+  ctx->infCount = infinite_count;
+  ctx->haveLights = true;
+  return DMT_OK;
+}
+
+int dmt_set_camera(dmt_ctx* ctx, const dmt_camera* cam) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if (!cam || cam->width <= 0 || cam->height <= 0 || cam->width > 65536 || cam->height > 65536)
+    return fail(ctx, DMT_ERR_INVALID, "dmt_set_camera: bad camera / resolution");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ctx->cam = *cam;
+  float m[16];
+  cameraFromRaster(cam->focal_length, cam->sensor_size, uint32_t(cam->width), uint32_t(cam->height), m);
+  memcpy(ctx->xf.cfr, m, sizeof(m));
+  worldFromCamera(cam->dir, cam->pos, m);
+  memcpy(ctx->xf.rfc, m, sizeof(m));
+  ctx->sp = computeSamplerParams(cam->width, cam->height);
+  if (cam->width != ctx->filmW || cam->height != ctx->filmH) {
+    if (ctx->ownFilm) {
+      (void)hipFree(ctx->d_mean);
+      (void)hipFree(ctx->d_m2);
+    }
+    ctx->d_mean = ctx->d_m2 = nullptr;
+    ctx->ownFilm = false;
+    size_t const bytes = size_t(cam->width) * size_t(cam->height) * sizeof(float4);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_mean), bytes));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_m2), bytes));
+    ctx->ownFilm = true;
+    ctx->filmW = cam->width, ctx->filmH = cam->height;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_mean, 0, bytes, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_m2, 0, bytes, ctx->stream));
+  }
+  ctx->haveCamera = true;
+  return DMT_OK;
+}
+
+int dmt_set_limits(dmt_ctx* ctx, int max_depth) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if (max_depth < 0) return fail(ctx, DMT_ERR_INVALID, "dmt_set_limits: max_depth < 0");
+  ctx->maxDepth = max_depth;
+  return DMT_OK;
+}
+
+int dmt_set_accel(dmt_ctx* ctx, int mode) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if (mode != DMT_ACCEL_BRUTE_FORCE)
+    return fail(ctx, DMT_ERR_INVALID, "dmt_set_accel: only DMT_ACCEL_BRUTE_FORCE is built in this revision");
+  ctx->accel = mode;
+  return DMT_OK;
+}
+
+int dmt_set_partition(dmt_ctx* ctx, int rank, int world) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if (world < 1 || rank < 0 || rank >= world) return fail(ctx, DMT_ERR_INVALID, "dmt_set_partition: bad rank/world");
+  ctx->rank = rank, ctx->world = world;
+  return DMT_OK;
+}
+
+int dmt_set_stream(dmt_ctx* ctx, void* hip_stream) {
+  if (!ctx) return DMT_ERR_INVALID;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->ownStream;
+  return DMT_OK;
+}
+
+int dmt_film_clear(dmt_ctx* ctx) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if (!ctx->d_mean) return fail(ctx, DMT_ERR_STATE, "dmt_film_clear: no film (call dmt_set_camera first)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t const bytes = size_t(ctx->filmW) * size_t(ctx->filmH) * sizeof(float4);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_mean, 0, bytes, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_m2, 0, bytes, ctx->stream));
+  return DMT_OK;
+}
+
+int dmt_film_bind(dmt_ctx* ctx, void* d_mean, void* d_m2) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if (!ctx->haveCamera) return fail(ctx, DMT_ERR_STATE, "dmt_film_bind: call dmt_set_camera first");
+  if (!d_mean || !d_m2) return fail(ctx, DMT_ERR_INVALID, "dmt_film_bind: null buffer");
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->ownFilm) {
+    (void)hipFree(ctx->d_mean);
+    (void)hipFree(ctx->d_m2);
+    ctx->ownFilm = false;
+  }
+  ctx->d_mean = static_cast<float4*>(d_mean);
+  ctx->d_m2 = static_cast<float4*>(d_m2);
+  return DMT_OK;
+}
+
+int dmt_film_device_ptrs(dmt_ctx* ctx, void** d_mean, void** d_m2) {
+  if (!ctx || !d_mean || !d_m2) return DMT_ERR_INVALID;
+  *d_mean = ctx->d_mean, *d_m2 = ctx->d_m2;
+  return DMT_OK;
+}
+
+int dmt_download_film(dmt_ctx* ctx, float* mean4, float* m24) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if (!ctx->d_mean) return fail(ctx, DMT_ERR_STATE, "dmt_download_film: no film");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t const bytes = size_t(ctx->filmW) * size_t(ctx->filmH) * sizeof(float4);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (mean4) HIP_TRY(ctx, hipMemcpy(mean4, ctx->d_mean, bytes, hipMemcpyDeviceToHost));
+  if (m24) HIP_TRY(ctx, hipMemcpy(m24, ctx->d_m2, bytes, hipMemcpyDeviceToHost));
+  return DMT_OK;
+}
+
+int dmt_render(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if (!(ctx->haveTris && ctx->haveBsdfs && ctx->haveLights && ctx->haveCamera))
+    return fail(ctx, DMT_ERR_STATE, "dmt_render: upload triangles, bsdfs, lights and set the camera first");
+  // the Halton index sample * stride must stay inside int32 (CC/private/rng.cu:229)
+  uint64_t const stride = uint64_t(ctx->sp.scale0) * uint64_t(ctx->sp.scale1);
+  if ((uint64_t(sample_offset) + spp + 1) * stride > 0x7FFFFFFFull)
+    return fail(ctx, DMT_ERR_INVALID, "dmt_render: sample index overflows the 32-bit Halton index");
+  // every material index must address an uploaded BSDF (the kernel gathers bsdfs[matId])
+  if (ctx->triCount > 0 && ctx->maxMatId >= ctx->bsdfCount)
+    return fail(ctx, DMT_ERR_INVALID, "dmt_render: a triangle's material index is outside the BSDF array");
+  if (x0 < 0) x0 = 0;
+  if (y0 < 0) y0 = 0;
+  if (x1 > ctx->filmW) x1 = ctx->filmW;
+  if (y1 > ctx->filmH) y1 = ctx->filmH;
+  if (spp == 0 || x1 <= x0 || y1 <= y0) return DMT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+  RenderParams P{};
+  P.scene = sceneView(ctx);
+  P.cam = ctx->xf;
+  P.sp = ctx->sp;
+  P.mean = ctx->d_mean, P.m2 = ctx->d_m2, P.counter = ctx->d_counter;
+  P.width = ctx->filmW, P.height = ctx->filmH;
+  P.x0 = x0, P.y0 = y0, P.x1 = x1, P.y1 = y1;
+  P.tx0 = x0 / 8, P.ty0 = y0 / 8;
+  int const tx1 = (x1 + 7) / 8, ty1 = (y1 + 7) / 8;
+  P.rtx = tx1 - P.tx0;
+  uint32_t const tiles = uint32_t(P.rtx) * uint32_t(ty1 - P.ty0);
+  P.rank = ctx->rank, P.world = ctx->world;
+  P.numItems = tiles > uint32_t(ctx->rank) ? (tiles - uint32_t(ctx->rank) + uint32_t(ctx->world) - 1) / uint32_t(ctx->world) : 0;
+  P.sampleOffset = sample_offset, P.spp = spp;
+  P.maxDepth = ctx->maxDepth;
+  if (P.numItems == 0) return DMT_OK;
+
+  uint32_t const wavesWanted = P.numItems;
+  uint32_t blocks = uint32_t(ctx->cuCount) * uint32_t(ctx->blocksPerCU);
+  uint32_t const blocksNeeded = (wavesWanted + 3) / 4;
+  if (blocks > blocksNeeded) blocks = blocksNeeded;
+  if (blocks == 0) blocks = 1;
+
+  if (ctx->eventsUsed == ctx->events.size()) {
+    hipEvent_t a, b;
+    HIP_TRY(ctx, hipEventCreate(&a));
+    HIP_TRY(ctx, hipEventCreate(&b));
+    ctx->events.emplace_back(a, b);
+  }
+  auto& ev = ctx->events[ctx->eventsUsed];
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
+  hipLaunchKernelGGL(k_megakernel, dim3(blocks), dim3(256), 0, ctx->stream, P);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
+  ++ctx->eventsUsed;
+  return DMT_OK;
+}
+
+int dmt_sync(dmt_ctx* ctx) {
+  if (!ctx) return DMT_ERR_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return DMT_OK;
+}
+
+int dmt_kernel_time(dmt_ctx* ctx, double* total_ms, uint64_t* launches, int reset) {
+  if (!ctx) return DMT_ERR_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < ctx->eventsUsed; ++i) {
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
+    ctx->accumMs += double(ms);
+    ++ctx->accumLaunches;
+  }
+  ctx->eventsUsed = 0;
+  if (total_ms) *total_ms = ctx->accumMs;
+  if (launches) *launches = ctx->accumLaunches;
+  if (reset) ctx->accumMs = 0.0, ctx->accumLaunches = 0;
+  return DMT_OK;
+}
+
+int dmt_kernel_info(dmt_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* blocks_per_cu, int* cu_count) {
+  if (!ctx) return DMT_ERR_INVALID;
+  hipFuncAttributes attr{};
+  HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<void const*>(k_megakernel)));
+  if (vgprs) *vgprs = attr.numRegs;
+  if (sgprs) *sgprs = 0;
+  if (lds_bytes) *lds_bytes = int(attr.sharedSizeBytes);
+  if (blocks_per_cu) *blocks_per_cu = ctx->blocksPerCU;
+  if (cu_count) *cu_count = ctx->cuCount;
+  return DMT_OK;
+}
+
+// ---- device unit-test entry points --------------------------------------------------------------
+int dmt_test_triangle_intersect(dmt_ctx* ctx, const float* xs, const float* ys, const float* zs,
+                                size_t count, const float* o3, const float* d3, int32_t* hit, float* t,
+                                float* pos3, float* nrm3, float* err3) {
+  if (!ctx || !xs || !ys || !zs || !o3 || !d3 || !hit) return DMT_ERR_INVALID;
+  if (count == 0) return DMT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Scratch S(ctx);
+  float* dx = S.up(xs, 4 * count);
+  float* dy = S.up(ys, 4 * count);
+  float* dz = S.up(zs, 4 * count);
+  int32_t* dh = S.up<int32_t>(nullptr, count);
+  float* dt = S.up<float>(nullptr, count);
+  float* dp = S.up<float>(nullptr, 3 * count);
+  float* dn = S.up<float>(nullptr, 3 * count);
+  float* de = S.up<float>(nullptr, 3 * count);
+  SCRATCH_CHECK(ctx, dx && dy && dz && dh && dt && dp && dn && de);
+  uint32_t const n = uint32_t(count);
+  hipLaunchKernelGGL(k_test_tri, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dx, dy, dz, n,
+                     f3{o3[0], o3[1], o3[2]}, f3{d3[0], d3[1], d3[2]}, dh, dt, dp, dn, de);
+  int rc = finishTest(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(hit, dh, count * 4, hipMemcpyDeviceToHost));
+  if (t) HIP_TRY(ctx, hipMemcpy(t, dt, count * 4, hipMemcpyDeviceToHost));
+  if (pos3) HIP_TRY(ctx, hipMemcpy(pos3, dp, count * 12, hipMemcpyDeviceToHost));
+  if (nrm3) HIP_TRY(ctx, hipMemcpy(nrm3, dn, count * 12, hipMemcpyDeviceToHost));
+  if (err3) HIP_TRY(ctx, hipMemcpy(err3, de, count * 12, hipMemcpyDeviceToHost));
+  return DMT_OK;
+}
+
+int dmt_test_sampler(dmt_ctx* ctx, int width, int height, int n, const int32_t* pxs, const int32_t* pys,
+                     const int32_t* ss, int ndims, int32_t* halton_index, float* pixel2d_out, float* dims) {
+  if (!ctx || n < 0 || ndims < 0 || !pxs || !pys || !ss || !halton_index || !pixel2d_out || !dims || width <= 0 || height <= 0)
+    return DMT_ERR_INVALID;
+  if (n == 0) return DMT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Scratch S(ctx);
+  int32_t* dpx = S.up(pxs, size_t(n));
+  int32_t* dpy = S.up(pys, size_t(n));
+  int32_t* dss = S.up(ss, size_t(n));
+  int32_t* dh = S.up<int32_t>(nullptr, size_t(n));
+  float* dp2 = S.up<float>(nullptr, 2 * size_t(n));
+  float* dd = S.up<float>(nullptr, size_t(n) * size_t(ndims));
+  SCRATCH_CHECK(ctx, dpx && dpy && dss && dh && dp2 && dd);
+  hipLaunchKernelGGL(k_test_sampler, dim3((n + 63) / 64), dim3(64), 0, ctx->stream,
+                     computeSamplerParams(width, height), n, dpx, dpy, dss, ndims, dh, dp2, dd);
+  int rc = finishTest(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(halton_index, dh, size_t(n) * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(pixel2d_out, dp2, size_t(n) * 8, hipMemcpyDeviceToHost));
+  if (ndims) HIP_TRY(ctx, hipMemcpy(dims, dd, size_t(n) * size_t(ndims) * 4, hipMemcpyDeviceToHost));
+  return DMT_OK;
+}
+
+int dmt_test_camera_rays(dmt_ctx* ctx, int n, const int32_t* pxs, const int32_t* pys, const int32_t* ss,
+                         float* o3, float* d3) {
+  if (!ctx || n < 0 || !pxs || !pys || !ss || !o3 || !d3) return DMT_ERR_INVALID;
+  if (!ctx->haveCamera) return fail(ctx, DMT_ERR_STATE, "dmt_test_camera_rays: set the camera first");
+  if (n == 0) return DMT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Scratch S(ctx);
+  int32_t* dpx = S.up(pxs, size_t(n));
+  int32_t* dpy = S.up(pys, size_t(n));
+  int32_t* dss = S.up(ss, size_t(n));
+  float* dO = S.up<float>(nullptr, 3 * size_t(n));
+  float* dD = S.up<float>(nullptr, 3 * size_t(n));
+  SCRATCH_CHECK(ctx, dpx && dpy && dss && dO && dD);
+  hipLaunchKernelGGL(k_test_camera, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->xf, ctx->sp, n, dpx,
+                     dpy, dss, dO, dD);
+  int rc = finishTest(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(o3, dO, size_t(n) * 12, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(d3, dD, size_t(n) * 12, hipMemcpyDeviceToHost));
+  return DMT_OK;
+}
+
+int dmt_test_bsdf(dmt_ctx* ctx, const void* bsdf32, int n, const float* ns3, const float* wo3,
+                  const float* u2, const float* uc, const float* wi_eval3, float* prepared12,
+                  float* sample10, float* eval4) {
+  if (!ctx || n < 0 || !bsdf32 || !ns3 || !wo3 || !u2 || !uc || !wi_eval3 || !prepared12 || !sample10 || !eval4)
+    return DMT_ERR_INVALID;
+  if (n == 0) return DMT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Scratch S(ctx);
+  float* dns = S.up(ns3, 3 * size_t(n));
+  float* dwo = S.up(wo3, 3 * size_t(n));
+  float* du2 = S.up(u2, 2 * size_t(n));
+  float* duc = S.up(uc, size_t(n));
+  float* dwi = S.up(wi_eval3, 3 * size_t(n));
+  float* dp = S.up<float>(nullptr, 12 * size_t(n));
+  float* ds = S.up<float>(nullptr, 10 * size_t(n));
+  float* de = S.up<float>(nullptr, 4 * size_t(n));
+  SCRATCH_CHECK(ctx, dns && dwo && du2 && duc && dwi && dp && ds && de);
+  Rec32 rec;
+  memcpy(&rec, bsdf32, 32);
+  hipLaunchKernelGGL(k_test_bsdf, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, rec, n, dns, dwo, du2, duc,
+                     dwi, dp, ds, de);
+  int rc = finishTest(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(prepared12, dp, size_t(n) * 48, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(sample10, ds, size_t(n) * 40, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(eval4, de, size_t(n) * 16, hipMemcpyDeviceToHost));
+  return DMT_OK;
+}
+
+int dmt_test_light(dmt_ctx* ctx, const void* light32, int n, const float* pos3, const float* nrm3,
+                   const float* u2, const int32_t* had_transmission, float* out14) {
+  if (!ctx || n < 0 || !light32 || !pos3 || !nrm3 || !u2 || !had_transmission || !out14) return DMT_ERR_INVALID;
+  if (n == 0) return DMT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Scratch S(ctx);
+  float* dp = S.up(pos3, 3 * size_t(n));
+  float* dn = S.up(nrm3, 3 * size_t(n));
+  float* du = S.up(u2, 2 * size_t(n));
+  int32_t* dh = S.up(had_transmission, size_t(n));
+  float* dout = S.up<float>(nullptr, 14 * size_t(n));
+  SCRATCH_CHECK(ctx, dp && dn && du && dh && dout);
+  Rec32 rec;
+  memcpy(&rec, light32, 32);
+  hipLaunchKernelGGL(k_test_light, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, rec, n, dp, dn, du, dh, dout);
+  int rc = finishTest(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(out14, dout, size_t(n) * 56, hipMemcpyDeviceToHost));
+  return DMT_OK;
+}
+
+int dmt_test_half(dmt_ctx* ctx, int n, const float* f_in, uint16_t* h_out, const uint16_t* h_in, float* f_out) {
+  if (!ctx || n < 0) return DMT_ERR_INVALID;
+  if (n == 0) return DMT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Scratch S(ctx);
+  float* dfi = f_in ? S.up(f_in, size_t(n)) : nullptr;
+  uint16_t* dho = h_out ? S.up<uint16_t>(nullptr, size_t(n)) : nullptr;
+  uint16_t* dhi = h_in ? S.up(h_in, size_t(n)) : nullptr;
+  float* dfo = f_out ? S.up<float>(nullptr, size_t(n)) : nullptr;
+  if ((f_in && !dfi) || (h_out && !dho) || (h_in && !dhi) || (f_out && !dfo))
+    return fail(ctx, DMT_ERR_HIP, "scratch allocation / upload failed");
+  hipLaunchKernelGGL(k_test_half, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, dfi, dho, dhi, dfo);
+  int rc = finishTest(ctx);
+  if (rc) return rc;
+  if (h_out && f_in) HIP_TRY(ctx, hipMemcpy(h_out, dho, size_t(n) * 2, hipMemcpyDeviceToHost));
+  if (f_out && h_in) HIP_TRY(ctx, hipMemcpy(f_out, dfo, size_t(n) * 4, hipMemcpyDeviceToHost));
+  return DMT_OK;
+}
+
+int dmt_test_trace_samples(dmt_ctx* ctx, int n, const int32_t* pxs, const int32_t* pys, const int32_t* ss,
+                           float* L3) {
+  if (!ctx || n < 0 || !pxs || !pys || !ss || !L3) return DMT_ERR_INVALID;
+  if (!(ctx->haveTris && ctx->haveBsdfs && ctx->haveLights && ctx->haveCamera))
+    return fail(ctx, DMT_ERR_STATE, "dmt_test_trace_samples: scene/camera not set");
+  if (ctx->triCount > 0 && ctx->maxMatId >= ctx->bsdfCount)
+    return fail(ctx, DMT_ERR_INVALID, "dmt_test_trace_samples: material index outside the BSDF array");
+  if (n == 0) return DMT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Scratch S(ctx);
+  int32_t* dpx = S.up(pxs, size_t(n));
+  int32_t* dpy = S.up(pys, size_t(n));
+  int32_t* dss = S.up(ss, size_t(n));
+  float* dL = S.up<float>(nullptr, 3 * size_t(n));
+  SCRATCH_CHECK(ctx, dpx && dpy && dss && dL);
+  hipLaunchKernelGGL(k_test_trace, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, sceneView(ctx), ctx->xf,
+                     ctx->sp, ctx->maxDepth, n, dpx, dpy, dss, dL);
+  int rc = finishTest(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(L3, dL, size_t(n) * 12, hipMemcpyDeviceToHost));
+  return DMT_OK;
+}
+
+int dmt_test_closest_hit(dmt_ctx* ctx, int nrays, const float* o3, const float* d3, int32_t* tri_index, float* t) {
+  if (!ctx || nrays < 0 || !o3 || !d3 || !tri_index || !t) return DMT_ERR_INVALID;
+  if (!ctx->haveTris) return fail(ctx, DMT_ERR_STATE, "dmt_test_closest_hit: upload triangles first");
+  if (nrays == 0) return DMT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Scratch S(ctx);
+  float* dO = S.up(o3, 3 * size_t(nrays));
+  float* dD = S.up(d3, 3 * size_t(nrays));
+  int32_t* di = S.up<int32_t>(nullptr, size_t(nrays));
+  float* dt = S.up<float>(nullptr, size_t(nrays));
+  SCRATCH_CHECK(ctx, dO && dD && di && dt);
+  hipLaunchKernelGGL(k_test_closest, dim3((nrays + 63) / 64), dim3(64), 0, ctx->stream, sceneView(ctx), nrays,
+                     dO, dD, di, dt);
+  int rc = finishTest(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(tri_index, di, size_t(nrays) * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(t, dt, size_t(nrays) * 4, hipMemcpyDeviceToHost));
+  return DMT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,367 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs, against the committed golden vectors, and through size-independent properties at
+larger sizes.  Integer / index work must be bit-exact; floating point within the stated tolerance.
+
+Float tolerance: the north star asks for per-pixel RMSE < 1e-3 against the reference arithmetic at
+equal sample indices.  The device build contracts a*b+c into FMAs and uses the device libm, so
+values differ from the oracle's by a few ulp, and a handful of paths per million flip a discrete
+decision (Russian roulette, edge hits).  The asserted bounds below are therefore the task's 1e-3
+on RMSE plus much tighter bounds on what actually is observed (typically ~1e-6).
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, film_rmse, golden
+from test_oracle_pins import RAY_A, RAY_B, reference_triangle_soup
+
+pytestmark = pytest.mark.gpu
+
+PINS = json.loads((GOLDEN / "reference_pins.json").read_text())
+RMSE_TOL = 1e-3          # north_star / BASELINE.json
+REL = 2e-5               # per-value relative tolerance for function-level float comparisons
+
+
+def close(a, b, rel=REL, abs_=1e-6):
+    return np.allclose(a, b, rtol=rel, atol=abs_, equal_nan=True)
+
+
+# ---- integer / index work: bit exact -------------------------------------------------------------
+def test_half_codec_exhaustive(renderer, O):
+    halves = np.arange(65536, dtype=np.uint16)
+    _, f = renderer.test_half(halves=halves)
+    L = O.lib()
+    ref = np.array([L.oracle_half_to_float(int(h)) for h in halves], np.float32)
+    assert np.array_equal(f.view(np.uint32), ref.view(np.uint32))
+    rng = np.random.default_rng(1)
+    x = np.concatenate([
+        rng.standard_normal(50000).astype(np.float32),
+        (rng.random(20000, dtype=np.float32) * 1e-4),
+        (rng.standard_normal(5000) * 1e5).astype(np.float32),
+        # exact ties between neighbouring halves (software codec rounds them UP)
+        (1.0 + (2 * np.arange(512) + 1) * 2.0 ** -11).astype(np.float32),
+        np.array([0.0, -0.0, 65504.0, 65520.0, 65536.0, 1e6, 6e-8, 3e-8, 2.9e-8, 6.1e-5, np.inf, -np.inf], np.float32),
+    ])
+    h, _ = renderer.test_half(floats=x)
+    ref = np.array([L.oracle_float_to_half(float(v)) for v in x], np.uint16)
+    assert np.array_equal(h, ref)
+
+
+@pytest.mark.parametrize("res", [512, 1024, 4096])
+def test_sampler_bit_exact_vs_golden_and_oracle(renderer, O, res):
+    g = golden("sampler_streams.npz")
+    hi, p2, d = renderer.test_sampler(res, res, g[f"r{res}_px"], g[f"r{res}_py"], g[f"r{res}_s"], 24)
+    assert np.array_equal(hi, g[f"r{res}_hidx"])
+    assert np.array_equal(p2.view(np.uint32), g[f"r{res}_pix2d"].view(np.uint32))
+    assert np.array_equal(d.view(np.uint32), g[f"r{res}_dims"].view(np.uint32))
+    rng = np.random.default_rng(res)
+    n = 4096
+    pxs, pys = rng.integers(0, res, n), rng.integers(0, res, n)
+    ss = rng.integers(0, 4096, n)
+    a = renderer.test_sampler(res, res, pxs, pys, ss, 10)
+    b = O.sampler_stream(res, res, pxs, pys, ss, 10)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+def test_sampler_ragged_resolution(renderer, O):
+    """width/height below 128 and non powers: scales stop early (rng.cu:194)."""
+    for w, h in ((37, 21), (64, 64), (100, 300), (1, 1)):
+        rng = np.random.default_rng(w * 1000 + h)
+        n = 512
+        pxs, pys, ss = rng.integers(0, w, n), rng.integers(0, h, n), rng.integers(0, 2000, n)
+        a = renderer.test_sampler(w, h, pxs, pys, ss, 9)
+        b = O.sampler_stream(w, h, pxs, pys, ss, 9)
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (w, h)
+
+
+# ---- the reference's own kernel test, on the GPU --------------------------------------------------
+@pytest.mark.parametrize("ray", [RAY_A, RAY_B], ids=["rayA", "rayB"])
+def test_reference_triangle_kat_on_gpu(renderer, O, ray):
+    """T/tests/triangle_intersect.cu:164-186: device hit flags == host Moeller-Trumbore for all
+    65,536 generated triangles (4 shapes incl. degenerate) and both rays."""
+    xs, ys, zs = reference_triangle_soup(1 << 16)
+    hit, t, pos, nrm, err = renderer.test_triangle_intersect(xs, ys, zs, *ray)
+    expected = O.host_intersect_mt(xs, ys, zs, *ray)
+    assert np.array_equal(hit, expected)
+    ohit, ot, opos, onrm, oerr = O.triangle_intersect(xs, ys, zs, *ray)
+    assert np.array_equal(hit, ohit)
+    m = hit == 1
+    assert close(t[m], ot[m]) and close(pos[m], opos[m]) and close(nrm[m], onrm[m]) and close(err[m], oerr[m], abs_=1e-12)
+
+
+def test_triangle_intersect_random_soup(renderer, O):
+    rng = np.random.default_rng(7)
+    n = 20000
+    c = rng.uniform(-1, 1, (n, 3))
+    v = c[:, None, :] + rng.uniform(-0.5, 0.5, (n, 3, 3))
+    xs = np.zeros((n, 4), np.float32); ys = np.zeros((n, 4), np.float32); zs = np.zeros((n, 4), np.float32)
+    xs[:, :3], ys[:, :3], zs[:, :3] = v[..., 0], v[..., 1], v[..., 2]
+    o = np.array([0.1, -3.0, 0.2], np.float32)
+    d = np.array([0.05, 1.0, -0.02], np.float32); d /= np.linalg.norm(d)
+    hit, t, pos, nrm, err = renderer.test_triangle_intersect(xs, ys, zs, o, d)
+    ohit, ot, opos, onrm, oerr = O.triangle_intersect(xs, ys, zs, o, d)
+    # a ray within float rounding of an edge may flip; count them (none expected at this size)
+    assert (hit != ohit).sum() <= 2
+    m = (hit == 1) & (ohit == 1)
+    assert m.sum() > 1000
+    assert close(t[m], ot[m], rel=1e-4) and close(pos[m], opos[m], rel=1e-4, abs_=1e-5)
+    assert close(nrm[m], onrm[m]) and close(err[m], oerr[m], rel=1e-3, abs_=1e-10)
+
+
+def test_closest_hit_lowest_index_on_ties(renderer, O):
+    """Duplicate triangles: the strict `<` of megakernel.cu:126 keeps the lowest index."""
+    g = golden("cornell_scene.npz")
+    xs = np.concatenate([g["xs"], g["xs"]]); ys = np.concatenate([g["ys"], g["ys"]]); zs = np.concatenate([g["zs"], g["zs"]])
+    mat = np.concatenate([g["mat_id"], g["mat_id"]])
+    renderer.upload_triangles(xs, ys, zs, mat)
+    rng = np.random.default_rng(3)
+    n = 4096
+    o = np.tile(np.array([0, 0.1, 0.3], np.float32), (n, 1))
+    d = rng.normal(size=(n, 3)).astype(np.float32); d[:, 1] = np.abs(d[:, 1]) + 0.2
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    idx, t = renderer.test_closest_hit(o, d)
+    oidx, ot = O.closest_hit(xs, ys, zs, o, d)
+    assert (idx != oidx).sum() <= 2
+    assert idx.max() < 26            # never the duplicate
+    m = idx == oidx
+    assert close(t[m], ot[m], rel=1e-5)
+
+
+# ---- function-level float parity -------------------------------------------------------------------
+@pytest.mark.parametrize("res", [64, 512, 1024])
+def test_camera_rays(renderer, O, res):
+    g = golden("camera_rays.npz")
+    scene = O.cornell_box(res, res)
+    renderer.set_camera(scene.camera)
+    o, d = renderer.test_camera_rays(g[f"r{res}_px"], g[f"r{res}_py"], g[f"r{res}_s"])
+    assert close(o, g[f"r{res}_o"]) and close(d, g[f"r{res}_d"], rel=1e-6, abs_=2e-7)
+    rng = np.random.default_rng(res)
+    pxs, pys, ss = rng.integers(0, res, 2048), rng.integers(0, res, 2048), rng.integers(0, 1024, 2048)
+    o, d = renderer.test_camera_rays(pxs, pys, ss)
+    oo, od = O.camera_rays(scene, pxs, pys, ss)
+    assert close(o, oo) and close(d, od, rel=1e-6, abs_=2e-7)
+
+
+def _decode_prepared(rec32, n):
+    """weight / multiScatter / energyScale of the oracle's prepared 32-byte records."""
+    rec = rec32.reshape(n, 32)
+    h = rec.view(np.uint16).reshape(n, 16)
+    f = rec.view(np.float32).reshape(n, 8)
+    weight = h[:, 0:3].view(np.float16).astype(np.float32)
+    ms = h[:, 7:10].view(np.float16).astype(np.float32)
+    return weight, ms, f[:, 2]
+
+
+BSDF_NAMES = [f"cornell{i}" for i in range(7)] + ["gold", "gold_aniso", "lambert", "glass_iso"]
+
+
+@pytest.mark.parametrize("name", BSDF_NAMES)
+def test_bsdf_prepare_sample_eval(renderer, name):
+    g = golden("bsdf_lattice.npz")
+    n = g["ns"].shape[0]
+    prep, samp, ev = renderer.test_bsdf(g[f"{name}_rec"], g["ns"], g["wo"], g["u2"], g["uc"], g["wi"])
+    gw, gms, gescale = _decode_prepared(g[f"{name}_prepared"], n)
+    btype = int(g[f"{name}_rec"].view(np.uint16)[3])
+    # fp16-quantised terms: equal up to one fp16 ulp on the rare rounding-boundary case
+    assert np.mean(prep[:, 0:3] != gw) < 0.02 and close(prep[:, 0:3], gw, rel=1.1e-3)
+    if btype == 0:
+        assert np.mean(prep[:, 3:6] != gms) < 0.02 and close(prep[:, 3:6], gms, rel=1.1e-3, abs_=1e-7)
+    if btype in (1, 2):
+        assert close(prep[:, 6], gescale, rel=1e-5)
+    gs, ge = g[f"{name}_sample"], g[f"{name}_eval"]
+    # discrete outputs (lobe choice, delta flag, validity) must agree except on knife-edge cases
+    flags_equal = (samp[:, 8:10] == gs[:, 8:10]).all(axis=1) & ((samp[:, 6] != 0) == (gs[:, 6] != 0))
+    assert flags_equal.mean() > 0.99
+    m = flags_equal
+    # wi / f / pdf inherit the fp16 quantisation of the weights only through f: 2e-3 relative
+    assert close(samp[m, 0:3], gs[m, 0:3], rel=1e-4, abs_=2e-6)
+    assert close(samp[m, 3:6], gs[m, 3:6], rel=2e-3, abs_=1e-6)
+    assert close(samp[m, 6], gs[m, 6], rel=1e-4, abs_=1e-7) and close(samp[m, 7], gs[m, 7])
+    assert close(ev, ge, rel=2e-3, abs_=1e-6)
+
+
+LIGHT_NAMES = ["cornell_spot", "wide_spot", "point_small", "point_big", "directional", "env"]
+
+
+@pytest.mark.parametrize("name", LIGHT_NAMES)
+def test_light_sample_eval(renderer, name):
+    g = golden("light_lattice.npz")
+    out = renderer.test_light(g[f"{name}_rec"], g["pos"], g["nrm"], g["u2"], g["hadt"])
+    ref = g[f"{name}_out"]
+    valid_equal = out[:, 13] == ref[:, 13]
+    assert valid_equal.mean() > 0.99
+    m = valid_equal & (ref[:, 13] == 1)
+    assert m.sum() > 0
+    assert close(out[m, 3:6], ref[m, 3:6], rel=1e-4, abs_=2e-6)                # direction
+    assert close(out[m, 6:8], ref[m, 6:8], rel=1e-4)                             # pdf, delta
+    assert close(out[m, 8], ref[m, 8], rel=1e-4) and close(out[m, 9], ref[m, 9])  # distance, factor
+    assert close(out[m, 10:13], ref[m, 10:13], rel=2e-4, abs_=1e-7)              # Le
+    finite = np.isfinite(ref[m, 0:3]).all(axis=1)
+    assert close(out[m][finite, 0:3], ref[m][finite, 0:3], rel=1e-4, abs_=1e-5)  # pLight
+
+
+# ---- per-path and film parity ---------------------------------------------------------------------
+def _load_cornell(renderer, O, w, h, max_depth=32):
+    scene = O.cornell_box(w, h)
+    renderer.upload_scene(scene)
+    renderer.set_limits(max_depth)
+    renderer.set_partition(0, 1)
+    renderer.film_clear()
+    return scene
+
+
+def test_path_radiance_samples(renderer, O):
+    g = golden("path_samples.npz")
+    _load_cornell(renderer, O, 64, 64)
+    L = renderer.test_trace_samples(g["px"], g["py"], g["s"])
+    ref = g["L"]
+    same = np.isclose(L, ref, rtol=1e-3, atol=1e-5).all(axis=1)
+    assert same.mean() >= 0.98, f"{(~same).sum()} of {len(same)} paths diverge"
+    assert np.isfinite(L).all()
+
+
+@pytest.mark.parametrize("w,h,spp,depth", [(64, 64, 4, 32), (64, 64, 64, 32), (64, 64, 16, 4), (37, 21, 8, 32), (128, 128, 16, 8)])
+def test_film_vs_oracle(renderer, O, w, h, spp, depth):
+    scene = _load_cornell(renderer, O, w, h, depth)
+    renderer.render(spp)
+    mean, m2 = renderer.download_film()
+    rmean, rm2 = O.render(scene, spp, max_depth=depth)
+    assert np.isfinite(mean).all() and np.isfinite(m2).all()
+    assert np.array_equal(m2[..., 3], rm2[..., 3])                 # sample counts: exact
+    assert np.all(mean[..., 3] == 0)
+    rmse = film_rmse(mean, rmean)
+    assert rmse < RMSE_TOL, rmse
+    assert rmse < 1e-4, rmse                                        # observed ~1e-6
+    # per-pixel: almost every pixel agrees to float rounding
+    bad = np.abs(mean[..., :3] - rmean[..., :3]).max(axis=2) > 1e-4
+    assert bad.mean() < 0.01, bad.mean()
+    assert film_rmse(np.sqrt(np.maximum(m2, 0)), np.sqrt(np.maximum(rm2, 0))) < 1e-2
+
+
+def test_film_vs_golden(renderer, O):
+    g = golden("films.npz")
+    _load_cornell(renderer, O, 64, 64)
+    renderer.render(64)
+    mean, _ = renderer.download_film()
+    assert film_rmse(mean, g["f64_spp64_mean"]) < 1e-4
+    _load_cornell(renderer, O, 512, 512)
+    renderer.render(4, region=(0, 200, 512, 232))
+    mean, m2 = renderer.download_film()
+    assert film_rmse(mean[200:232], g["f512_band_spp4_mean"]) < 1e-4
+    assert np.all(m2[:200, :, 3] == 0) and np.all(m2[232:, :, 3] == 0)   # untouched outside the region
+
+
+def test_empty_and_degenerate_inputs(renderer, O):
+    scene = _load_cornell(renderer, O, 16, 16)
+    renderer.render(0)                                   # zero samples: no-op
+    renderer.render(4, region=(5, 5, 5, 9))              # empty region: no-op
+    mean, m2 = renderer.download_film()
+    assert not mean.any() and not m2.any()
+    # empty scene: every ray misses, film = environment colour exactly
+    renderer.upload_triangles(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32),
+                              np.zeros((0, 4), np.float32), np.zeros(0, np.uint32))
+    renderer.render(3)
+    mean, m2 = renderer.download_film()
+    env = np.float16(0.1).astype(np.float32)
+    assert np.all(mean[..., :3] == env) and np.all(m2[..., 3] == 3) and np.all(m2[..., :3] == 0)
+    # depth cap 0: first hit terminates with no light gathered
+    renderer.upload_scene(scene)
+    renderer.set_limits(0)
+    renderer.film_clear()
+    renderer.render(2)
+    mean, _ = renderer.download_film()
+    rmean, _ = O.render(scene, 2, max_depth=0)
+    assert film_rmse(mean, rmean) < 1e-6
+    renderer.set_limits(32)
+
+
+def test_error_behaviour(renderer, pkg, O):
+    scene = O.cornell_box(16, 16)
+    with pkg.Renderer(0) as r2:
+        with pytest.raises(pkg.DmtError):          # render before upload
+            r2.render(1)
+        r2.upload_scene(scene)
+        bad = scene.mat_id.copy(); bad[3] = 99
+        r2.upload_triangles(scene.xs, scene.ys, scene.zs, bad)
+        with pytest.raises(pkg.DmtError):          # material index outside the BSDF array
+            r2.render(1)
+        with pytest.raises(pkg.DmtError):          # sample index beyond the 32-bit Halton index
+            r2.upload_triangles(scene.xs, scene.ys, scene.zs, scene.mat_id)
+            r2.render(10, sample_offset=70000)
+        with pytest.raises(pkg.DmtError):
+            r2.set_partition(2, 2)
+
+
+# ---- size-independent properties at larger sizes --------------------------------------------------
+def test_resumable_bit_exact(renderer, O):
+    """kspp batching (main.cu:141-155): 8 launches of 8 spp give the same bits as one of 64."""
+    _load_cornell(renderer, O, 256, 256)
+    renderer.render(64)
+    a = renderer.download_film()
+    renderer.film_clear()
+    for k in range(8):
+        renderer.render(8, sample_offset=8 * k)
+    b = renderer.download_film()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_tile_partition_is_exact(renderer, O):
+    """Multi-GPU split: rendering the tile sets of ranks 0..3 one after the other into one film
+    (disjoint pixels) equals the single-context film bit for bit; so does a sum of separate films."""
+    _load_cornell(renderer, O, 200, 120)
+    renderer.render(8)
+    full = renderer.download_film()
+    renderer.film_clear()
+    parts = []
+    for rank in range(4):
+        renderer.set_partition(rank, 4)
+        renderer.film_clear()
+        renderer.render(8)
+        parts.append(renderer.download_film())
+    renderer.set_partition(0, 1)
+    counts = sum(p[1][..., 3] for p in parts)
+    assert np.all(counts == 8)                                    # each pixel owned exactly once
+    assert np.array_equal(sum(p[0] for p in parts), full[0])      # x + 0 == x: exact gather by sum
+    assert np.array_equal(sum(p[1] for p in parts), full[1])
+
+
+def test_region_split_is_exact(renderer, O):
+    _load_cornell(renderer, O, 96, 80)
+    renderer.render(4)
+    full = renderer.download_film()
+    renderer.film_clear()
+    for reg in ((0, 0, 50, 33), (50, 0, 96, 33), (0, 33, 96, 80)):
+        renderer.render(4, region=reg)
+    split = renderer.download_film()
+    assert np.array_equal(full[0], split[0]) and np.array_equal(full[1], split[1])
+
+
+def test_published_sqrt_mse_figure_on_gpu(renderer, O):
+    """docs/notes.txt:36-37: `dmt-mk v2 ... 0.018148823657066993` = scripts/rmse.py default mode on
+    the CUDA build's output-2048_sqrt_mse.png (256x256, 2048 spp, kspp 4, depth 32).  The HIP path
+    must land on the same figure: this ties the whole pipeline (scene, sampler, BSDFs, lights, film,
+    8-bit writer) to the reference's own GPU output."""
+    p = PINS["published"]
+    _load_cornell(renderer, O, 256, 256)
+    for k in range(8):
+        renderer.render(256, sample_offset=256 * k)
+    mean, m2 = renderer.download_film()
+    assert np.all(m2[..., 3] == 2048)
+    _, se = O.pixels_from_film(mean, m2)
+    got = (se.astype(np.float64) / 255.0).mean(axis=2).mean()
+    assert abs(got - p["avg_sqrt_mse_256x256_2048spp"]) < 2e-6, got
+    assert abs(got - p["oracle_ltr_measured"]) < 2e-6, got
+
+
+def test_full_size_invariants(renderer, O):
+    """BASELINE config 2 resolution (1024x1024), reduced spp: finite, correct counts, mean matches
+    the oracle on a sampled band, image statistics match the 256x256 render."""
+    scene = _load_cornell(renderer, O, 1024, 1024, 8)
+    renderer.render(16)
+    mean, m2 = renderer.download_film()
+    assert np.isfinite(mean).all() and np.all(m2[..., 3] == 16) and (m2[..., :3] >= 0).all()
+    rmean, _ = O.render(scene, 16, max_depth=8, region=(0, 500, 1024, 516))
+    assert film_rmse(mean[500:516], rmean[500:516]) < 1e-4
