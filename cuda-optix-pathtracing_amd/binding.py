@@ -52,7 +52,7 @@ EXPORTED_SYMBOLS = [
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
     "dmt_render", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_test_triangle_intersect",
     "dmt_test_sampler", "dmt_test_camera_rays", "dmt_test_bsdf", "dmt_test_light", "dmt_test_half",
-    "dmt_test_trace_samples", "dmt_test_closest_hit",
+    "dmt_test_trace_samples", "dmt_test_trace_log", "dmt_test_closest_hit",
 ]
 
 
@@ -265,6 +265,14 @@ class Renderer:
         self._check(self._lib.dmt_test_trace_samples(self._ctx, n, _p(pxs), _p(pys), _p(ss), _p(out)),
                     "dmt_test_trace_samples")
         return out
+
+    def test_trace_log(self, px, py, s, cap=64):
+        rec = np.zeros((cap, 12), np.float32)
+        n = C.c_int()
+        L = np.zeros(3, np.float32)
+        self._check(self._lib.dmt_test_trace_log(self._ctx, int(px), int(py), int(s), _p(rec), int(cap), C.byref(n),
+                                                 _p(L)), "dmt_test_trace_log")
+        return rec[:n.value], L
 
     def test_closest_hit(self, o, d):
         o, d = _f32(o, (-1, 3)), _f32(d, (-1, 3))

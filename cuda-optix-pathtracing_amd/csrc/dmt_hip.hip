@@ -262,6 +262,42 @@ __global__ void k_test_trace(SceneView sc, CameraXf cam, SamplerParams sp, int m
   }
 }
 
+// single path with a per-bounce log {tri, pos3, beta3, L3 (before shading), depth, dim}
+__global__ void k_test_trace_log(SceneView sc, CameraXf cam, SamplerParams sp, int maxDepth, int px, int py,
+                                 int smp, float* rec12, int cap, int* nOut, float* L3) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  PathState st{};
+  path_begin(st, cam, sp, px, py, halton_pixel_base(sp, px, py), uint32_t(smp));
+  int n = 0;
+  for (;;) {
+    bool const doC = st.traceClosest, doS = st.hasShadow;
+    int bestTri;
+    float bu, bv;
+    bool occluded;
+    trace_pair_brute(sc, st, doC, doS, bestTri, bu, bv, occluded);
+    if (doS) {
+      if (!occluded) st.L = st.L + st.C;
+      st.hasShadow = false;
+    }
+    bool ended = true;
+    if (doC) {
+      if (n < cap) {
+        float* r = rec12 + 12 * n++;
+        f3 pos = mk3(0, 0, 0);
+        if (bestTri >= 0) pos = hit_finish(sc.post[bestTri], bu, bv, st.ray.d).pos;
+        r[0] = float(bestTri), r[1] = pos.x, r[2] = pos.y, r[3] = pos.z;
+        r[4] = st.beta.x, r[5] = st.beta.y, r[6] = st.beta.z, r[7] = st.L.x, r[8] = st.L.y, r[9] = st.L.z;
+        r[10] = float(st.depth), r[11] = float(st.rng.dim);
+      }
+      ended = path_shade(sc, maxDepth, st, bestTri, bu, bv);
+      if (ended) st.traceClosest = false;
+    }
+    if (ended && !st.hasShadow) break;
+  }
+  *nOut = n;
+  L3[0] = st.L.x, L3[1] = st.L.y, L3[2] = st.L.z;
+}
+
 __global__ void k_test_tri(float const* xs, float const* ys, float const* zs, uint32_t n, f3 o, f3 d,
                            int32_t* hit, float* t, float* pos3, float* nrm3, float* err3) {
   uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1040,6 +1076,28 @@ int dmt_test_trace_samples(dmt_ctx* ctx, int n, const int32_t* pxs, const int32_
   int rc = finishTest(ctx);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpy(L3, dL, size_t(n) * 12, hipMemcpyDeviceToHost));
+  return DMT_OK;
+}
+
+int dmt_test_trace_log(dmt_ctx* ctx, int px, int py, int s, float* rec12, int cap, int* n_out, float* L3) {
+  if (!ctx || !rec12 || cap <= 0 || !n_out || !L3) return DMT_ERR_INVALID;
+  if (!(ctx->haveTris && ctx->haveBsdfs && ctx->haveLights && ctx->haveCamera))
+    return fail(ctx, DMT_ERR_STATE, "dmt_test_trace_log: scene/camera not set");
+  if (ctx->triCount > 0 && ctx->maxMatId >= ctx->bsdfCount)
+    return fail(ctx, DMT_ERR_INVALID, "dmt_test_trace_log: material index outside the BSDF array");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  Scratch S(ctx);
+  float* dr = S.up<float>(nullptr, 12 * size_t(cap));
+  int* dn = S.up<int>(nullptr, 1);
+  float* dL = S.up<float>(nullptr, 3);
+  SCRATCH_CHECK(ctx, dr && dn && dL);
+  hipLaunchKernelGGL(k_test_trace_log, dim3(1), dim3(64), 0, ctx->stream, sceneView(ctx), ctx->xf, ctx->sp,
+                     ctx->maxDepth, px, py, s, dr, cap, dn, dL);
+  int rc = finishTest(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(rec12, dr, size_t(cap) * 48, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(n_out, dn, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(L3, dL, 12, hipMemcpyDeviceToHost));
   return DMT_OK;
 }
 

@@ -136,6 +136,10 @@ int dmt_test_half(dmt_ctx* ctx, int n, const float* f_in, uint16_t* h_out, const
 /* radiance of individual (pixel, sample) paths of the uploaded scene */
 int dmt_test_trace_samples(dmt_ctx* ctx, int n, const int32_t* pxs, const int32_t* pys,
                            const int32_t* ss, float* L3);
+/* per-bounce log of one path: records of 12 floats {tri, pos3, beta3, L3 before shading, depth,
+ * sampler dimension}; *n_out = records written (<= cap) */
+int dmt_test_trace_log(dmt_ctx* ctx, int px, int py, int s, float* rec12, int cap, int* n_out,
+                       float* L3);
 /* closest hit (triangle index or -1, t) of rays against the uploaded scene, current accel mode */
 int dmt_test_closest_hit(dmt_ctx* ctx, int nrays, const float* o3, const float* d3,
                          int32_t* tri_index, float* t);

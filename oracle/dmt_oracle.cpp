@@ -1407,7 +1407,19 @@ inline uint32_t pickIndex(float u, uint32_t count) {
 }
 
 // one path; returns radiance L                                      megakernel.cu:103-297
-V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats* st) {
+struct PathLog {  // optional per-bounce record sink: {tri, pos3, beta3, L3, depth, dim} = 12 floats
+  float* rec = nullptr;
+  int cap = 0, n = 0;
+  void push(int tri, V3 pos, V3 beta, V3 L, int depth, int dim) {
+    if (!rec || n >= cap) return;
+    float* r = rec + 12 * n++;
+    r[0] = float(tri), r[1] = pos.x, r[2] = pos.y, r[3] = pos.z, r[4] = beta.x, r[5] = beta.y, r[6] = beta.z;
+    r[7] = L.x, r[8] = L.y, r[9] = L.z, r[10] = float(depth), r[11] = float(dim);
+  }
+};
+
+V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats* st,
+             PathLog* log = nullptr) {
   Sampler rng;
   rng.startPixelSample(cfg.hp, px, py, s);
   Rec32 bsdf{};
@@ -1421,15 +1433,18 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
   if (st) st->samples++;
   while (true) {
     Hit hit;
+    int hitTri = -1;
     if (st) st->closestRays++, st->triTests += sc.triCount;
     for (uint64_t tri = 0; tri < sc.triCount; ++tri) {
       Hit const r = triangleIntersect(sc.xs + 4 * tri, sc.ys + 4 * tri, sc.zs + 4 * tri, ray);
       if (r.hit && r.t < hit.t) {
         hit = r;
+        hitTri = int(tri);
         hit.matId = sc.matId[tri];
         if (dot(ray.d, hit.normal) > 0) hit.normal *= -1.f;
       }
     }
+    if (log) log->push(hitTri, hit.pos, beta, L, depth, rng.dimension);
     if (!hit.hit) {
       if (sc.infLightCount > 0) {  // (reference reads out of bounds when the list is empty)
         uint32_t const li = pickIndex(rng.get1D(), sc.infLightCount);
@@ -1959,6 +1974,20 @@ void oracle_trace_samples(const OracleScene* s, const void* camera44, int maxDep
     V3 const L = tracePath(sc, cfg, pxs[i], pys[i], ss[i], nullptr);
     L3[3 * i] = L.x, L3[3 * i + 1] = L.y, L3[3 * i + 2] = L.z;
   }
+}
+
+// per-bounce log of one path: records of 12 floats {tri, pos3, beta3, L3 (before shading), depth, dim}
+int oracle_trace_log(const OracleScene* s, const void* camera44, int maxDepth, int px, int py, int smp,
+                     int rtlArgs, float* rec12, int cap, float* Lout3) {
+  Camera cam;
+  memcpy(&cam, camera44, sizeof(Camera));
+  Scene const sc = toScene(s);
+  RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
+  PathLog log;
+  log.rec = rec12, log.cap = cap;
+  V3 const L = tracePath(sc, cfg, px, py, smp, nullptr, &log);
+  Lout3[0] = L.x, Lout3[1] = L.y, Lout3[2] = L.z;
+  return log.n;
 }
 
 // 8-bit quantisation of the writers            CC/private/host_utils.cu:475-497

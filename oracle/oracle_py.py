@@ -310,3 +310,12 @@ def make_directional_light(color, direction, one_minus_cos):
 
 def make_env_light(color):
     return _rec(lib().oracle_make_env_light, _f3(color))
+
+
+def trace_log(scene, px, py, s, max_depth=32, rtl_args=False, cap=64):
+    rec = np.zeros((cap, 12), np.float32)
+    L = np.zeros(3, np.float32)
+    cs = scene.c_struct()
+    n = lib().oracle_trace_log(C.byref(cs), _p(scene.camera), int(max_depth), int(px), int(py), int(s),
+                               int(bool(rtl_args)), _p(rec), int(cap), _p(L))
+    return rec[:n], L
