@@ -15,3 +15,4 @@ from .binding import (  # noqa: F401
     library_path,
     load_library,
 )
+from . import host_scene  # noqa: F401,E402

@@ -1,0 +1,73 @@
+// dmt_host_c.cpp -- flat C view of the host-side scene library (for ctypes / other FFIs).
+#include <cstring>
+#include <new>
+
+#include "dmt_scene.hpp"
+
+using namespace dmt_host;
+
+extern "C" {
+
+struct dmt_host_scene {
+  Scene s;
+};
+
+dmt_host_scene* dmt_host_scene_cornell_box() {
+  auto* h = new (std::nothrow) dmt_host_scene();
+  if (h) h->s = cornellBox();
+  return h;
+}
+dmt_host_scene* dmt_host_scene_random_triangles(uint64_t count, uint64_t seed) {
+  auto* h = new (std::nothrow) dmt_host_scene();
+  if (h) h->s = randomTriangleScene(size_t(count), seed);
+  return h;
+}
+void dmt_host_scene_destroy(dmt_host_scene* h) { delete h; }
+
+uint64_t dmt_host_scene_triangle_count(const dmt_host_scene* h) { return h->s.triangleCount(); }
+uint32_t dmt_host_scene_bsdf_count(const dmt_host_scene* h) { return uint32_t(h->s.bsdfs.size()); }
+uint32_t dmt_host_scene_light_count(const dmt_host_scene* h) { return uint32_t(h->s.lights.size()); }
+uint32_t dmt_host_scene_infinite_light_count(const dmt_host_scene* h) { return uint32_t(h->s.infiniteLights.size()); }
+const float* dmt_host_scene_xs(const dmt_host_scene* h) { return h->s.xs.data(); }
+const float* dmt_host_scene_ys(const dmt_host_scene* h) { return h->s.ys.data(); }
+const float* dmt_host_scene_zs(const dmt_host_scene* h) { return h->s.zs.data(); }
+const uint32_t* dmt_host_scene_mat_ids(const dmt_host_scene* h) { return h->s.matId.data(); }
+const void* dmt_host_scene_bsdfs(const dmt_host_scene* h) { return h->s.bsdfs.data(); }
+const void* dmt_host_scene_lights(const dmt_host_scene* h) { return h->s.lights.data(); }
+const void* dmt_host_scene_infinite_lights(const dmt_host_scene* h) { return h->s.infiniteLights.data(); }
+dmt_camera* dmt_host_scene_camera(dmt_host_scene* h) { return &h->s.camera; }
+void dmt_host_scene_set_resolution(dmt_host_scene* h, int width, int height) {
+  h->s.camera.width = width, h->s.camera.height = height;
+}
+int dmt_host_scene_upload(const dmt_host_scene* h, dmt_ctx* ctx) { return uploadScene(ctx, h->s); }
+
+// packers, one 32-byte record out
+static void put(Packed32 const& p, void* out32) { memcpy(out32, p.bytes, 32); }
+static Vec3 v(const float* p) { return {p[0], p[1], p[2]}; }
+void dmt_host_make_lambert(void* out32) { put(makeLambert(), out32); }
+void dmt_host_make_oren_nayar(const float* color3, float roughness, void* out32) { put(makeOrenNayar(v(color3), roughness), out32); }
+void dmt_host_make_ggx_dielectric(const float* r3, const float* t3, float phi0, float eta, float ax, float ay, void* out32) {
+  put(makeGGXDielectric(v(r3), v(t3), phi0, eta, ax, ay), out32);
+}
+void dmt_host_make_ggx_conductor(const float* eta3, const float* k3, float phi0, float ax, float ay, void* out32) {
+  put(makeGGXConductor(v(eta3), v(k3), phi0, ax, ay), out32);
+}
+void dmt_host_make_point_light(const float* c3, const float* p3, float radius, void* out32) { put(makePointLight(v(c3), v(p3), radius), out32); }
+void dmt_host_make_spot_light(const float* c3, const float* p3, const float* d3, float cos0, float cosE, float radius, void* out32) {
+  put(makeSpotLight(v(c3), v(p3), v(d3), cos0, cosE, radius), out32);
+}
+void dmt_host_make_directional_light(const float* c3, const float* d3, float omc, void* out32) {
+  put(makeDirectionalLight(v(c3), v(d3), omc), out32);
+}
+void dmt_host_make_environmental_light(const float* c3, void* out32) { put(makeEnvironmentalLight(v(c3)), out32); }
+uint16_t dmt_host_float_to_half_bits(float f) { return float_to_half_bits(f); }
+float dmt_host_half_bits_to_float(uint16_t h) { return half_bits_to_float(h); }
+
+void dmt_host_film_to_rgb8(const float* mean4, const float* m24, uint64_t pixels, uint8_t* meanRgb, uint8_t* stdErrRgb) {
+  filmToRgb8(mean4, m24, size_t(pixels), meanRgb, stdErrRgb);
+}
+int dmt_host_write_mean_and_mse(const float* mean4, const float* m24, uint32_t width, uint32_t height, const char* baseName) {
+  return writeMeanAndMSERowMajor(mean4, m24, width, height, baseName) ? 0 : 1;
+}
+
+}  // extern "C"

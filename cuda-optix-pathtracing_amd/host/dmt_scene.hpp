@@ -1,0 +1,95 @@
+// dmt_scene.hpp -- host-side scene description above the C ABI (include/dmt_hip.h).
+//
+// Mirrors the reference's host interface for the megakernel path so that a caller of
+// cornellBox / make* / generate* (CC/public/cuda-core/host_utils.cuh:259-261,
+// CC/public/cuda-core/bsdf.cuh:94-101, CC/public/cuda-core/light.cuh:83-93,
+// CC/public/cuda-core/host_scene.cuh:26-48; CC = examples/triangles/cuda-core) finds the same
+// names, argument meaning and byte-identical packed records.  IEEE fp32 throughout.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/dmt_hip.h"
+
+namespace dmt_host {
+
+struct Vec3 {
+  float x = 0.f, y = 0.f, z = 0.f;
+};
+
+struct Packed32 {  // one BSDF or Light record as uploaded (32 bytes)
+  uint8_t bytes[32] = {};
+};
+
+struct Triangle {
+  Vec3 v0, v1, v2;
+};
+
+// storage codecs of the packed records (CC/private/encoding.cu)
+uint16_t float_to_half_bits(float f);
+float half_bits_to_float(uint16_t h);
+uint32_t octaFromDir(Vec3 dir);
+Vec3 dirFromOcta(uint32_t octa);
+
+// BSDF packers (CC/private/bsdf.cu:669-717,817-844)
+Packed32 makeLambert();
+Packed32 makeOrenNayar(Vec3 color, float roughness);
+Packed32 makeGGXDielectric(Vec3 reflectanceTint, Vec3 transmittanceTint, float phi0, float eta,
+                           float alphax, float alphay);
+Packed32 makeGGXConductor(Vec3 eta, Vec3 kappa, float phi0, float alphax, float alphay);
+// light packers (CC/private/light.cu:271-307)
+Packed32 makePointLight(Vec3 color, Vec3 position, float radius);
+Packed32 makeSpotLight(Vec3 color, Vec3 position, Vec3 direction, float cosTheta0, float cosThetaE,
+                       float radius);
+Packed32 makeDirectionalLight(Vec3 color, Vec3 direction, float oneMinusCosAngle);
+Packed32 makeEnvironmentalLight(Vec3 color);
+
+// procedural meshes (CC/private/host_scene.cu:7-119)
+std::vector<Triangle> generateSphereMesh(Vec3 center, float radius, int latSubdiv, int lonSubdiv);
+std::vector<Triangle> generateCube(Vec3 center, Vec3 scale);
+std::vector<Triangle> generatePlane(Vec3 center, Vec3 normal, float width, float height);
+
+// HostTriangleScene + everything else the upload helpers take, already flattened to the
+// TriangleSoup layout of triSoupFromTriangles (CC/private/host_utils.cu:118-187)
+struct Scene {
+  std::vector<float> xs, ys, zs;  // 4 floats per triangle {c0, c1, c2, 0}
+  std::vector<uint32_t> matId;
+  std::vector<Packed32> bsdfs, lights, infiniteLights;
+  dmt_camera camera{};
+
+  size_t triangleCount() const { return matId.size(); }
+  // addModel + the material walk of triSoupFromTriangles: the FIRST mesh always gets material 0
+  void addModel(std::vector<Triangle> const& mesh, uint32_t materialIndex);
+
+ private:
+  bool firstMesh_ = true;
+};
+
+// the reference's only scene (CC/private/host_utils.cu:402-469): 26 triangles, 7 materials,
+// one spot light, one constant environment; 256x256, camera at the origin looking down +y
+Scene cornellBox();
+
+// BASELINE config 4 / SURVEY 8d: deterministic random triangle soup in front of the Cornell camera
+// (splitmix64 seed 0x5EED1234, centroids in [-10,10]^3 shifted to y in [5,25], edges in
+// [-0.15,0.15]^3, material = index mod 7 over the Cornell BSDFs, spot light at (0,15,12), env 0.1)
+Scene randomTriangleScene(size_t triangleCount, uint64_t seed = 0x5EED1234ull);
+
+// 8-bit images of the film, exactly as the reference's writers quantise them
+// (CC/private/host_utils.cu:475-497): u8 = (uint8)min(max(v,0)*255, 255), linear, truncating;
+// standard-error image = sqrt(M2)/N
+void filmToRgb8(float const* mean4, float const* m24, size_t pixelCount, uint8_t* meanRgb,
+                uint8_t* stdErrRgb);
+// writes <base>.png and <base>_sqrt_mse.png (writeMeanAndMSERowMajor, host_utils.cu:246-269)
+bool writeMeanAndMSERowMajor(float const* mean4, float const* m24, uint32_t width, uint32_t height,
+                             std::string const& baseName, std::string* error = nullptr);
+bool writePngRgb8(std::string const& path, uint8_t const* rgb, uint32_t width, uint32_t height,
+                  std::string* error = nullptr);
+
+// upload a Scene through the C ABI (triSoupFromTriangles + deviceBSDF + deviceLights +
+// deviceCamera + allocateDeviceConstantMemory in the reference, megakernel/main.cu:110-117)
+int uploadScene(dmt_ctx* ctx, Scene const& scene);
+
+}  // namespace dmt_host

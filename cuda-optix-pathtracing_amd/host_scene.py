@@ -1,0 +1,111 @@
+"""ctypes view of host/libdmt_host.so: the C++ host side above the C ABI (scene builders, packers,
+writers).  Plumbing only."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_HOST = Path(__file__).resolve().parent / "host"
+_LIB = None
+
+
+def load_host_library():
+    global _LIB
+    if _LIB is None:
+        so = _HOST / "libdmt_host.so"
+        if not so.exists():
+            raise RuntimeError(f"{so} is missing: run __graft_entry__.build()")
+        lib = C.CDLL(str(so))
+        for name in ("dmt_host_scene_cornell_box", "dmt_host_scene_random_triangles", "dmt_host_scene_xs",
+                     "dmt_host_scene_ys", "dmt_host_scene_zs", "dmt_host_scene_mat_ids", "dmt_host_scene_bsdfs",
+                     "dmt_host_scene_lights", "dmt_host_scene_infinite_lights", "dmt_host_scene_camera"):
+            getattr(lib, name).restype = C.c_void_p
+        lib.dmt_host_scene_random_triangles.argtypes = [C.c_uint64, C.c_uint64]
+        lib.dmt_host_scene_triangle_count.restype = C.c_uint64
+        for name in ("dmt_host_scene_bsdf_count", "dmt_host_scene_light_count", "dmt_host_scene_infinite_light_count"):
+            getattr(lib, name).restype = C.c_uint32
+        lib.dmt_host_half_bits_to_float.restype = C.c_float
+        lib.dmt_host_half_bits_to_float.argtypes = [C.c_uint16]
+        lib.dmt_host_float_to_half_bits.restype = C.c_uint16
+        lib.dmt_host_float_to_half_bits.argtypes = [C.c_float]
+        _LIB = lib
+    return _LIB
+
+
+def _copy(ptr, dtype, count):
+    if count == 0:
+        return np.zeros(0, dtype)
+    n = count * np.dtype(dtype).itemsize
+    buf = (C.c_uint8 * n).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count).copy()
+
+
+class HostScene:
+    """Arrays of one scene in the upload layout (same attribute names the Renderer.upload_scene uses)."""
+
+    def __init__(self, handle):
+        L = load_host_library()
+        h = C.c_void_p(handle)
+        n = L.dmt_host_scene_triangle_count(h)
+        self.xs = _copy(L.dmt_host_scene_xs(h), np.float32, 4 * n).reshape(-1, 4)
+        self.ys = _copy(L.dmt_host_scene_ys(h), np.float32, 4 * n).reshape(-1, 4)
+        self.zs = _copy(L.dmt_host_scene_zs(h), np.float32, 4 * n).reshape(-1, 4)
+        self.mat_id = _copy(L.dmt_host_scene_mat_ids(h), np.uint32, n)
+        self.bsdfs = _copy(L.dmt_host_scene_bsdfs(h), np.uint8, 32 * L.dmt_host_scene_bsdf_count(h)).reshape(-1, 32)
+        self.lights = _copy(L.dmt_host_scene_lights(h), np.uint8, 32 * L.dmt_host_scene_light_count(h)).reshape(-1, 32)
+        self.inf_lights = _copy(L.dmt_host_scene_infinite_lights(h), np.uint8,
+                                32 * L.dmt_host_scene_infinite_light_count(h)).reshape(-1, 32)
+        self.camera = _copy(L.dmt_host_scene_camera(h), np.uint8, 44)
+        L.dmt_host_scene_destroy(h)
+
+    @property
+    def tri_count(self):
+        return int(self.mat_id.shape[0])
+
+    @property
+    def width(self):
+        return int(self.camera[24:28].view(np.int32)[0])
+
+    @property
+    def height(self):
+        return int(self.camera[28:32].view(np.int32)[0])
+
+    def set_resolution(self, w, h):
+        self.camera[24:32] = np.array([w, h], np.int32).view(np.uint8)
+        return self
+
+
+def cornell_box(width=None, height=None):
+    s = HostScene(load_host_library().dmt_host_scene_cornell_box())
+    if width is not None:
+        s.set_resolution(width, height if height is not None else width)
+    return s
+
+
+def random_triangle_scene(count, seed=0x5EED1234, width=None, height=None):
+    s = HostScene(load_host_library().dmt_host_scene_random_triangles(int(count), int(seed)))
+    if width is not None:
+        s.set_resolution(width, height if height is not None else width)
+    return s
+
+
+def film_to_rgb8(mean, m2):
+    mean = np.ascontiguousarray(mean, np.float32)
+    m2 = np.ascontiguousarray(m2, np.float32)
+    n = mean.size // 4
+    a = np.zeros((n, 3), np.uint8)
+    b = np.zeros((n, 3), np.uint8)
+    load_host_library().dmt_host_film_to_rgb8(mean.ctypes.data_as(C.c_void_p), m2.ctypes.data_as(C.c_void_p),
+                                              C.c_uint64(n), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+    shp = mean.shape[:-1] + (3,)
+    return a.reshape(shp), b.reshape(shp)
+
+
+def write_mean_and_mse(mean, m2, base_name):
+    mean = np.ascontiguousarray(mean, np.float32)
+    m2 = np.ascontiguousarray(m2, np.float32)
+    h, w = mean.shape[:2]
+    rc = load_host_library().dmt_host_write_mean_and_mse(mean.ctypes.data_as(C.c_void_p), m2.ctypes.data_as(C.c_void_p),
+                                                         C.c_uint32(w), C.c_uint32(h), str(base_name).encode())
+    if rc != 0:
+        raise RuntimeError(f"writing {base_name}.png failed")

@@ -1,0 +1,91 @@
+"""CPU tests of the C++ host side above the C ABI (scene builders, packers, writers): an
+implementation independent of the oracle's, compared byte for byte with the oracle's restatement of
+the reference's host code and with the golden scene."""
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import golden
+
+
+@pytest.fixture(scope="module")
+def H(pkg):
+    return pkg.host_scene
+
+
+def test_cornell_box_bytes_match_golden(H):
+    g = golden("cornell_scene.npz")
+    s = H.cornell_box()
+    assert np.array_equal(s.xs, g["xs"]) and np.array_equal(s.ys, g["ys"]) and np.array_equal(s.zs, g["zs"])
+    assert np.array_equal(s.mat_id, g["mat_id"])
+    assert np.array_equal(s.bsdfs, g["bsdfs"])
+    assert np.array_equal(s.lights, g["lights"]) and np.array_equal(s.inf_lights, g["inf_lights"])
+    assert np.array_equal(s.camera, g["camera"])
+
+
+def test_packers_match_oracle(H, O):
+    L = H.load_host_library()
+    import ctypes as C
+
+    def rec(fn, *a):
+        out = np.zeros(32, np.uint8)
+        fn(*a, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def f3(v):
+        return np.ascontiguousarray(v, np.float32).ctypes.data_as(C.c_void_p)
+
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        c, p, d = rng.random(3) * 2, rng.normal(size=3), rng.normal(size=3)
+        r, e, ax, ay, phi = rng.random() * 2, 1 + rng.random(), rng.random(), rng.random(), rng.random() * 7
+        cf = [C.c_float(float(x)) for x in (r, e, ax, ay, phi)]
+        assert np.array_equal(rec(L.dmt_host_make_oren_nayar, f3(c), cf[0]), O.make_oren_nayar(c, r))
+        assert np.array_equal(rec(L.dmt_host_make_ggx_dielectric, f3(c), f3(p * p), cf[4], cf[1], cf[2], cf[3]),
+                              O.make_ggx_dielectric(c, p * p, phi, e, ax, ay))
+        assert np.array_equal(rec(L.dmt_host_make_ggx_conductor, f3(c), f3(p * p), cf[4], cf[2], cf[3]),
+                              O.make_ggx_conductor(c, p * p, phi, ax, ay))
+        assert np.array_equal(rec(L.dmt_host_make_point_light, f3(c), f3(p), cf[0]), O.make_point_light(c, p, r))
+        assert np.array_equal(rec(L.dmt_host_make_spot_light, f3(c), f3(p), f3(d), cf[2], cf[3], cf[0]),
+                              O.make_spot_light(c, p, d, ax, ay, r))
+        assert np.array_equal(rec(L.dmt_host_make_directional_light, f3(c), f3(d), cf[2]),
+                              O.make_directional_light(c, d, ax))
+        assert np.array_equal(rec(L.dmt_host_make_environmental_light, f3(c)), O.make_env_light(c))
+    assert np.array_equal(rec(L.dmt_host_make_lambert), O.make_lambert())
+
+
+def test_half_codec_matches_oracle_exhaustively(H, O):
+    L, OL = H.load_host_library(), O.lib()
+    for h in range(0, 65536, 7):
+        assert L.dmt_host_half_bits_to_float(h) == OL.oracle_half_to_float(h) or (h & 0x7C00) == 0x7C00
+    rng = np.random.default_rng(2)
+    xs = np.concatenate([rng.standard_normal(4000), rng.random(2000) * 1e-4, 1.0 + (2 * np.arange(64) + 1) * 2.0 ** -11,
+                         [0.0, 65504.0, 65520.0, 1e6, 6e-8, 3e-8]]).astype(np.float32)
+    for x in xs:
+        assert L.dmt_host_float_to_half_bits(float(x)) == OL.oracle_float_to_half(float(x))
+
+
+def test_film_quantisation_and_png_writer(H, O, tmp_path):
+    rng = np.random.default_rng(9)
+    mean = (rng.random((20, 33, 4), dtype=np.float32) * 1.3 - 0.1).astype(np.float32)
+    m2 = rng.random((20, 33, 4), dtype=np.float32)
+    m2[..., 3] = 16
+    a, b = H.film_to_rgb8(mean, m2)
+    oa, ob = O.pixels_from_film(mean, m2)
+    assert np.array_equal(a, oa) and np.array_equal(b, ob)
+    # truncation, not rounding; clamped; linear (no gamma): host_utils.cu:475-485
+    assert a[0, 0, 0] == np.uint8(min(max(mean[0, 0, 0], 0) * 255, 255))
+    H.write_mean_and_mse(mean, m2, tmp_path / "output-16")
+    img = np.asarray(Image.open(tmp_path / "output-16.png").convert("RGB"))
+    se = np.asarray(Image.open(tmp_path / "output-16_sqrt_mse.png").convert("RGB"))
+    assert np.array_equal(img, a) and np.array_equal(se, b)
+
+
+def test_random_triangle_scene_is_deterministic(H):
+    a = H.random_triangle_scene(5000)
+    b = H.random_triangle_scene(5000)
+    assert np.array_equal(a.xs, b.xs) and a.tri_count == 5000
+    assert a.mat_id.max() == 6 and a.bsdfs.shape[0] == 7
+    c = np.stack([a.xs[:, :3].mean(1), a.ys[:, :3].mean(1), a.zs[:, :3].mean(1)], 1)
+    assert c[:, 1].min() > 4.8 and c[:, 1].max() < 25.2 and abs(c[:, 0]).max() < 10.2
+    assert H.random_triangle_scene(100, seed=1).xs[0, 0] != a.xs[0, 0]
