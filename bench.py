@@ -83,8 +83,12 @@ def main():
     scene = pkg.host_scene.cornell_box(width, height)
 
     r = pkg.Renderer(local_rank)
-    stream = torch.cuda.current_stream(dev)
-    r.set_stream(stream.cuda_stream)          # kernels + their HIP timing events go on torch's stream
+    # one explicit (non-null) stream for everything: film zeroing, kernels + their HIP timing events,
+    # and the RCCL reduce are ordered on it
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    r.set_stream(stream.cuda_stream)
     r.upload_scene(scene)
     r.set_limits(max_depth)
     r.set_partition(rank, world)
@@ -140,7 +144,8 @@ def main():
             oscene = O.cornell_box(width, height)
             rows = max(1, min(args.cpu_band_rows, height))
             y0 = (height - rows) // 2
-            threads = os.cpu_count() or 1
+            # the 1-GPU box exposes 256 logical CPUs but the job's CPU share is 16 cores
+            threads = int(os.environ.get("DMT_CPU_THREADS", min(os.cpu_count() or 1, 16)))
             tc = time.perf_counter()
             omean, om2, stats = O.render(oscene, spp, max_depth=max_depth, region=(0, y0, width, y0 + rows),
                                          threads=threads, want_stats=True)
