@@ -48,35 +48,50 @@ struct RenderParams {
   int maxDepth;
 };
 
+// Per-lane state.  A lane carries (a) the path it is currently extending and (b) at most one
+// pending shadow ray.  The shadow ray normally belongs to the current path, but when a path ends
+// with its last shadow ray still untraced the lane parks that sample's radiance in Lfin and starts
+// the NEXT sample at once: the old shadow ray and the new camera ray share the next triangle pass,
+// and the parked sample is finalised (in order) right after it.
 struct PathState {
-  Ray ray;
+  RayPair rp;       // .x = current path's ray, .y = pending shadow ray
   f3 beta, L;
   int depth;
   bool lastT;
-  bool traceClosest;
-  bool hasShadow;
-  Ray sray;
+  bool active;      // has a closest-hit ray to trace
+  bool hasShadow;   // shadow ray / smax / C valid
+  bool finPending;  // the pending shadow ray belongs to the finished sample parked in Lfin
   float smax;
   f3 C;
+  f3 Lfin;
   Sampler rng;
 };
+DMT_DEV f3 ray_dir(PathState const& st) { return mk3(st.rp.dx.x, st.rp.dy.x, st.rp.dz.x); }
+DMT_DEV void set_ray(PathState& st, f3 o, f3 d) {
+  st.rp.ox.x = o.x, st.rp.oy.x = o.y, st.rp.oz.x = o.z;
+  st.rp.dx.x = d.x, st.rp.dy.x = d.y, st.rp.dz.x = d.z;
+}
+DMT_DEV void set_shadow_ray(PathState& st, f3 o, f3 d) {
+  st.rp.ox.y = o.x, st.rp.oy.y = o.y, st.rp.oz.y = o.z;
+  st.rp.dx.y = d.x, st.rp.dy.y = d.y, st.rp.dz.y = d.z;
+}
 
 DMT_DEV void path_begin(PathState& st, CameraXf const& cam, SamplerParams const& sp, int px, int py,
                         int32_t pixBase, uint32_t s) {
   int32_t const hidx = pixBase + int32_t(s) * (sp.scale0 * sp.scale1);
   st.rng.start(uint32_t(hidx));
-  st.ray = camera_ray(cam, sp, px, py, hidx);
+  Ray const r = camera_ray(cam, sp, px, py, hidx);
+  set_ray(st, r.o, r.d);
   st.beta = mk3(1, 1, 1);
   st.L = mk3(0, 0, 0);
   st.depth = 0;
   st.lastT = false;
-  st.traceClosest = true;
-  st.hasShadow = false;
+  st.active = true;
 }
 
 // Everything between two ray casts (T/megakernel/megakernel.cu:135-295).  Returns true when the
-// path ends.  May leave a pending shadow ray (st.hasShadow) whose contribution st.C is added by
-// the caller once visibility is known.
+// path ends.  May leave a pending shadow ray (st.hasShadow) whose contribution st.C is added once
+// visibility is known.
 DMT_DEV bool path_shade(SceneView const& sc, int maxDepth, PathState& st, int bestTri, float bu,
                         float bv) {
   if (bestTri < 0) {  // miss: constant environment, no MIS (megakernel.cu:135-151)
@@ -90,8 +105,9 @@ DMT_DEV bool path_shade(SceneView const& sc, int maxDepth, PathState& st, int be
   }
   if (st.depth >= maxDepth) return true;  // :154-158
 
-  Hit const hit = hit_finish(sc.post[bestTri], bu, bv, st.ray.d);
-  f3 const wo = -st.ray.d;
+  f3 const rd = ray_dir(st);
+  Hit const hit = hit_finish(sc.post[bestTri], bu, bv, rd);
+  f3 const wo = -rd;
   Bsdf const b = bsdf_prepare(sc.bsdfs[hit.matId], hit.normal, wo);  // :165-166
 
   // next-event estimation (:170-241)
@@ -113,8 +129,7 @@ DMT_DEV bool path_shade(SceneView const& sc, int maxDepth, PathState& st, int be
           float const w = sqr(pmf * ls.pdf) / sqr(pmf * ls.pdf + bsdfPdf);
           st.C = Le * f * st.beta * w;
         }
-        st.sray.o = offset_ray_origin(hit.pos, hit.error, hit.normal, ls.direction);
-        st.sray.d = ls.direction;
+        set_shadow_ray(st, offset_ray_origin(hit.pos, hit.error, hit.normal, ls.direction), ls.direction);
         st.smax = ls.distance;
         st.hasShadow = true;
       }
@@ -128,8 +143,7 @@ DMT_DEV bool path_shade(SceneView const& sc, int maxDepth, PathState& st, int be
   BsdfSample const bs = sample_bsdf(b, wo, hit.normal, hit.normal, u2, uc);
   if (!bs.valid()) return true;
   st.lastT = bs.refract;
-  st.ray.o = offset_ray_origin(hit.pos, hit.error, hit.normal, bs.wi);
-  st.ray.d = bs.wi;
+  set_ray(st, offset_ray_origin(hit.pos, hit.error, hit.normal, bs.wi), bs.wi);
   st.beta = st.beta * (bs.f * fabsf(dot(bs.wi, hit.normal)) / bs.pdf);
   float const rrBeta = max3(st.beta * bs.eta);
   if (rrBeta < 1 && st.depth > 1) {
@@ -141,52 +155,84 @@ DMT_DEV bool path_shade(SceneView const& sc, int maxDepth, PathState& st, int be
   return false;
 }
 
-// One pass over the triangle array for up to two rays per lane: closest hit for st.ray and
-// any-hit for st.sray.  Brute force; loop index is wave-uniform -> scalar loads.
+DMT_DEV TriS load_tri(TriIsect const DMT_CONST_AS* tris, uint32_t i) {
+  TriS T;
+  T.p0x = tris[i].p0x, T.p0y = tris[i].p0y, T.p0z = tris[i].p0z;
+  T.e0x = tris[i].e0x, T.e0y = tris[i].e0y, T.e0z = tris[i].e0z;
+  T.e1x = tris[i].e1x, T.e1y = tris[i].e1y, T.e1z = tris[i].e1z;
+  return T;
+}
+
+// One pass over the triangle array for the lane's ray pair: closest hit for .x, any-hit for .y.
+// Brute force = the reference's semantics.  The loop index is wave-uniform and the array is read
+// through the constant address space, so each triangle arrives by s_load into SGPRs (prefetched one
+// iteration ahead) and the VALU work is packed fp32 over the two rays: no VGPR, LDS or
+// vector-memory traffic in the loop.
 DMT_DEV void trace_pair_brute(SceneView const& sc, PathState const& st, bool doC, bool doS,
                               int& bestTri, float& bu, float& bv, bool& occluded) {
   float bt = kInf;
   bestTri = -1;
   bu = 0.f, bv = 0.f;
   occluded = false;
-  for (uint32_t i = 0; i < sc.triCount; ++i) {
-    TriIsect const T = sc.tris[i];
-    MTResult const r1 = mt_test(T, st.ray);
-    MTResult const r2 = mt_test(T, st.sray);
-    if (doC && r1.valid && r1.t < bt) {  // strict <: lowest index wins ties (megakernel.cu:126)
-      bt = r1.t;
+  auto const* tris = to_const_as(sc.tris);
+  uint32_t const n = sc.triCount;
+  TriS cur = load_tri(tris, 0);  // the array always holds >= 1 record (devAlloc)
+  for (uint32_t i = 0; i < n; ++i) {
+    TriS const nxt = load_tri(tris, i + 1 < n ? i + 1 : i);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch s_loads above the arithmetic
+    MTPair const m = mt_pair(cur, st.rp);
+    bool const v1 = mt_valid(m.det.x, m.t.x, m.u.x, m.v.x);
+    bool const v2 = mt_valid(m.det.y, m.t.y, m.u.y, m.v.y);
+    if (doC && v1 && m.t.x < bt) {  // strict <: lowest index wins ties (megakernel.cu:126)
+      bt = m.t.x;
       bestTri = int(i);
-      bu = r1.u;
-      bv = r1.v;
+      bu = m.u.x;
+      bv = m.v.x;
     }
-    if (doS && r2.valid && r2.t < st.smax) occluded = true;  // :210-211
+    if (doS && v2 && m.t.y < st.smax) occluded = true;  // :210-211
+    cur = nxt;
   }
 }
 
-// Advance one lane by one "ray pass".  Returns true when the sample is complete (st.L final).
-DMT_DEV bool path_advance(SceneView const& sc, int maxDepth, PathState& st, bool alive) {
-  bool const doC = alive && st.traceClosest;
-  bool const doS = alive && st.hasShadow;
+// One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
+// sink(L) is called once per completed sample, in sample order.
+template <class Sink>
+DMT_DEV void lane_step(SceneView const& sc, int maxDepth, PathState& st, Sink&& sink) {
+  bool const doC = st.active;
+  bool const doS = st.hasShadow;
   int bestTri;
   float bu, bv;
   bool occluded;
   trace_pair_brute(sc, st, doC, doS, bestTri, bu, bv, occluded);
   if (doS) {
-    if (!occluded) st.L = st.L + st.C;
     st.hasShadow = false;
+    if (st.finPending) {  // the shadow ray of an already finished sample
+      if (!occluded) st.Lfin = st.Lfin + st.C;
+      st.finPending = false;
+      sink(st.Lfin);
+    } else if (!occluded) {
+      st.L = st.L + st.C;  // NEE of the previous bounce, added before anything of this bounce
+    }
   }
-  bool ended = false;
   if (doC) {
-    ended = path_shade(sc, maxDepth, st, bestTri, bu, bv);
-    if (ended) st.traceClosest = false;
-  } else if (alive) {
-    ended = true;  // was only waiting for its last shadow ray
+    if (path_shade(sc, maxDepth, st, bestTri, bu, bv)) {
+      st.active = false;
+      if (st.hasShadow) {  // last NEE still untraced: park the sample, the lane may start the next
+        st.Lfin = st.L;
+        st.finPending = true;
+      } else {
+        sink(st.L);
+      }
+    }
   }
-  return alive && ended && !st.hasShadow;
 }
+
+// running film statistics of the lane's pixel, in LDS as [field][thread]: touched once per sample
+__shared__ float s_film[7 * kLdsThreads];
 
 __global__ void __launch_bounds__(256) k_megakernel(RenderParams P) {
   int const lane = int(threadIdx.x) & 63;
+  float* const film = s_film + threadIdx.x;
   for (;;) {
     uint32_t item = 0;
     if (lane == 0) item = atomicAdd(P.counter, 1u);
@@ -200,46 +246,42 @@ __global__ void __launch_bounds__(256) k_megakernel(RenderParams P) {
     bool const inside = px >= P.x0 && px < P.x1 && py >= P.y0 && py < P.y1;
     size_t const pidx = size_t(px) + size_t(py) * size_t(P.width);
 
-    f3 mean = mk3(0, 0, 0), M2 = mk3(0, 0, 0);
-    float N = 0.f;
     int32_t pixBase = 0;
-    if (inside) {  // SMEMLayout::startSample, T/megakernel/megakernel.cuh:45-57
-      float4 const m = P.mean[pidx];
-      float4 const v = P.m2[pidx];
-      mean = mk3(m.x, m.y, m.z);
-      M2 = mk3(v.x, v.y, v.z);
-      N = v.w;
-      pixBase = halton_pixel_base(P.sp, px, py);
+    {  // SMEMLayout::startSample, T/megakernel/megakernel.cuh:45-57
+      float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
+      if (inside) {
+        m = P.mean[pidx];
+        v = P.m2[pidx];
+        pixBase = halton_pixel_base(P.sp, px, py);
+      }
+      film[0 * kLdsThreads] = m.x, film[1 * kLdsThreads] = m.y, film[2 * kLdsThreads] = m.z;
+      film[3 * kLdsThreads] = v.x, film[4 * kLdsThreads] = v.y, film[5 * kLdsThreads] = v.z;
+      film[6 * kLdsThreads] = v.w;
     }
-    uint32_t s = P.sampleOffset;
-    uint32_t const sEnd = P.sampleOffset + P.spp;
+    uint32_t sNext = P.sampleOffset;
+    uint32_t const sEnd = inside ? P.sampleOffset + P.spp : P.sampleOffset;
     PathState st{};
-    bool needNew = true;
-    bool alive = inside;
+    auto welford = [&](f3 L) {  // SMEMLayout::updateSample, megakernel.cuh:59-79
+      f3 mean = mk3(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads]);
+      f3 M2 = mk3(film[3 * kLdsThreads], film[4 * kLdsThreads], film[5 * kLdsThreads]);
+      float const N = film[6 * kLdsThreads] + 1.0f;
+      f3 const delta = L - mean;
+      mean = mean + delta / N;
+      f3 const delta2 = L - mean;
+      M2 = M2 + delta * delta2;
+      film[0 * kLdsThreads] = mean.x, film[1 * kLdsThreads] = mean.y, film[2 * kLdsThreads] = mean.z;
+      film[3 * kLdsThreads] = M2.x, film[4 * kLdsThreads] = M2.y, film[5 * kLdsThreads] = M2.z;
+      film[6 * kLdsThreads] = N;
+    };
     for (;;) {
-      if (alive && needNew) {
-        if (s < sEnd) {
-          path_begin(st, P.cam, P.sp, px, py, pixBase, s);
-          needNew = false;
-        } else {
-          alive = false;
-        }
-      }
-      if (!__any(alive)) break;
-      if (path_advance(P.scene, P.maxDepth, st, alive)) {
-        // Welford update, megakernel.cuh:59-79
-        N += 1.0f;
-        f3 const delta = st.L - mean;
-        mean = mean + delta / N;
-        f3 const delta2 = st.L - mean;
-        M2 = M2 + delta * delta2;
-        ++s;
-        needNew = true;
-      }
+      if (!st.active && sNext < sEnd) path_begin(st, P.cam, P.sp, px, py, pixBase, sNext++);
+      if (!__any(st.active || st.hasShadow)) break;
+      lane_step(P.scene, P.maxDepth, st, welford);
     }
     if (inside) {  // endSample, megakernel.cuh:81-85
-      P.mean[pidx] = make_float4(mean.x, mean.y, mean.z, 0.f);
-      P.m2[pidx] = make_float4(M2.x, M2.y, M2.z, N);
+      P.mean[pidx] = make_float4(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads], 0.f);
+      P.m2[pidx] = make_float4(film[3 * kLdsThreads], film[4 * kLdsThreads], film[5 * kLdsThreads],
+                               film[6 * kLdsThreads]);
     }
   }
 }
@@ -250,15 +292,12 @@ __global__ void __launch_bounds__(256) k_megakernel(RenderParams P) {
 __global__ void k_test_trace(SceneView sc, CameraXf cam, SamplerParams sp, int maxDepth, int n,
                              int32_t const* pxs, int32_t const* pys, int32_t const* ss, float* L3) {
   int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
-  bool alive = i < n;
   PathState st{};
-  if (alive) path_begin(st, cam, sp, pxs[i], pys[i], halton_pixel_base(sp, pxs[i], pys[i]), uint32_t(ss[i]));
+  if (i < n) path_begin(st, cam, sp, pxs[i], pys[i], halton_pixel_base(sp, pxs[i], pys[i]), uint32_t(ss[i]));
+  auto store = [&](f3 L) { L3[3 * i] = L.x, L3[3 * i + 1] = L.y, L3[3 * i + 2] = L.z; };
   for (;;) {
-    if (!__any(alive)) break;
-    if (path_advance(sc, maxDepth, st, alive)) {
-      L3[3 * i] = st.L.x, L3[3 * i + 1] = st.L.y, L3[3 * i + 2] = st.L.z;
-      alive = false;
-    }
+    if (!__any(st.active || st.hasShadow)) break;
+    lane_step(sc, maxDepth, st, store);
   }
 }
 
@@ -270,7 +309,7 @@ __global__ void k_test_trace_log(SceneView sc, CameraXf cam, SamplerParams sp, i
   path_begin(st, cam, sp, px, py, halton_pixel_base(sp, px, py), uint32_t(smp));
   int n = 0;
   for (;;) {
-    bool const doC = st.traceClosest, doS = st.hasShadow;
+    bool const doC = st.active, doS = st.hasShadow;
     int bestTri;
     float bu, bv;
     bool occluded;
@@ -284,13 +323,13 @@ __global__ void k_test_trace_log(SceneView sc, CameraXf cam, SamplerParams sp, i
       if (n < cap) {
         float* r = rec12 + 12 * n++;
         f3 pos = mk3(0, 0, 0);
-        if (bestTri >= 0) pos = hit_finish(sc.post[bestTri], bu, bv, st.ray.d).pos;
+        if (bestTri >= 0) pos = hit_finish(sc.post[bestTri], bu, bv, ray_dir(st)).pos;
         r[0] = float(bestTri), r[1] = pos.x, r[2] = pos.y, r[3] = pos.z;
         r[4] = st.beta.x, r[5] = st.beta.y, r[6] = st.beta.z, r[7] = st.L.x, r[8] = st.L.y, r[9] = st.L.z;
         r[10] = float(st.depth), r[11] = float(st.rng.dim);
       }
       ended = path_shade(sc, maxDepth, st, bestTri, bu, bv);
-      if (ended) st.traceClosest = false;
+      if (ended) st.active = false;
     }
     if (ended && !st.hasShadow) break;
   }
@@ -400,15 +439,16 @@ __global__ void k_test_closest(SceneView sc, int n, float const* o3, float const
   int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
   bool const alive = i < n;
   PathState st{};
-  if (alive) {
-    st.ray.o = mk3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
-    st.ray.d = mk3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
-  }
-  float bt = kInf;
-  int best = -1;
-  for (uint32_t k = 0; k < sc.triCount; ++k) {
-    MTResult const r = mt_test(sc.tris[k], st.ray);
-    if (alive && r.valid && r.t < bt) bt = r.t, best = int(k);
+  if (alive)
+    set_ray(st, mk3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), mk3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]));
+  st.active = alive;
+  int best;
+  float bu, bv, bt = kInf;
+  bool occluded;
+  trace_pair_brute(sc, st, alive, false, best, bu, bv, occluded);
+  if (alive && best >= 0) {  // t of the winning triangle (same arithmetic as the loop)
+    TriS const T = load_tri(to_const_as(sc.tris), uint32_t(best));
+    bt = mt_pair(T, st.rp).t.x;
   }
   if (alive) tri[i] = best, tOut[i] = bt;
 }

@@ -181,6 +181,18 @@ struct SamplerParams {  // CC types.cuh:93-97
   int32_t inv0, inv1;
 };
 
+// Pointer in the constant address space: a wave-uniform index then becomes an s_load (scalar cache,
+// result in SGPRs) no matter what the kernel stores elsewhere; a divergent index still becomes an
+// ordinary global_load.  The scene arrays are never written by a kernel.
+#define DMT_CONST_AS __attribute__((address_space(4)))
+template <class T>
+__host__ __device__ inline T const DMT_CONST_AS* to_const_as(T const* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (T const DMT_CONST_AS*)p;
+#pragma clang diagnostic pop
+}
+
 struct SceneView {
   TriIsect const* __restrict__ tris;
   TriPost const* __restrict__ post;
@@ -269,31 +281,29 @@ DMT_DEV int32_t halton_pixel_base(SamplerParams const& p, int px, int py) {
   return idx;
 }
 
+// The 8 values of a sample live in LDS as [dimension][thread] (bank-conflict free: consecutive lanes
+// hit consecutive banks), one 4-byte read per draw instead of 8 VGPRs + a select chain per draw.
+// Every thread only ever touches its own column, so no barrier is needed.
+constexpr int kLdsThreads = 256;  // threads per block of every kernel that traces paths
+__shared__ float s_sampler_u[8 * kLdsThreads];
+
 struct Sampler {
-  float u0, u1, u2, u3, u4, u5, u6, u7;  // sampleDim(2..9, haltonIndex)
   int dim;
 
   DMT_DEV void start(uint32_t haltonIndex) {
-    u0 = sample_dim<2, 5>(haltonIndex);
-    u1 = sample_dim<3, 7>(haltonIndex);
-    u2 = sample_dim<4, 11>(haltonIndex);
-    u3 = sample_dim<5, 13>(haltonIndex);
-    u4 = sample_dim<6, 17>(haltonIndex);
-    u5 = sample_dim<7, 19>(haltonIndex);
-    u6 = sample_dim<8, 23>(haltonIndex);
-    u7 = sample_dim<9, 29>(haltonIndex);
+    float* const u = s_sampler_u + threadIdx.x;
+    u[0 * kLdsThreads] = sample_dim<2, 5>(haltonIndex);
+    u[1 * kLdsThreads] = sample_dim<3, 7>(haltonIndex);
+    u[2 * kLdsThreads] = sample_dim<4, 11>(haltonIndex);
+    u[3 * kLdsThreads] = sample_dim<5, 13>(haltonIndex);
+    u[4 * kLdsThreads] = sample_dim<6, 17>(haltonIndex);
+    u[5 * kLdsThreads] = sample_dim<7, 19>(haltonIndex);
+    u[6 * kLdsThreads] = sample_dim<8, 23>(haltonIndex);
+    u[7 * kLdsThreads] = sample_dim<9, 29>(haltonIndex);
     dim = 2;
   }
   DMT_DEV float pick(int d) const {  // d in 2..9
-    float r = u0;
-    r = d == 3 ? u1 : r;
-    r = d == 4 ? u2 : r;
-    r = d == 5 ? u3 : r;
-    r = d == 6 ? u4 : r;
-    r = d == 7 ? u5 : r;
-    r = d == 8 ? u6 : r;
-    r = d == 9 ? u7 : r;
-    return r;
+    return s_sampler_u[(d - 2) * kLdsThreads + int(threadIdx.x)];
   }
   DMT_DEV float get1D() {  // rng.cu:233-240
     if (dim >= 10) dim = 2;
@@ -363,7 +373,9 @@ DMT_DEV MTResult mt_test(f3 p0, f3 e0, f3 e1, Ray const& ray) {
   f3 const dxe1 = mk3(ray.d.y * e1.z - ray.d.z * e1.y, ray.d.z * e1.x - ray.d.x * e1.z,
                       ray.d.x * e1.y - ray.d.y * e1.x);
   float const det = dxe1.x * e0.x + dxe1.y * e0.y + dxe1.z * e0.z;
-  float const invDet = 1.0f / det;
+  // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: this is the hot loop, and the
+  // reference's own GPU build divides with -use_fast_math (cmake/Config.cmake:465)
+  float const invDet = __builtin_amdgcn_rcpf(det);
   f3 const ov = mk3(ray.o.x - p0.x, ray.o.y - p0.y, ray.o.z - p0.z);
   f3 const txe0 = mk3(ov.y * e0.z - ov.z * e0.y, ov.z * e0.x - ov.x * e0.z,
                       ov.x * e0.y - ov.y * e0.x);
@@ -378,6 +390,42 @@ DMT_DEV MTResult mt_test(f3 p0, f3 e0, f3 e1, Ray const& ray) {
 }
 DMT_DEV MTResult mt_test(TriIsect const& T, Ray const& ray) {
   return mt_test(mk3(T.p0x, T.p0y, T.p0z), mk3(T.e0x, T.e0y, T.e0z), mk3(T.e1x, T.e1y, T.e1z), ray);
+}
+
+// Two rays per lane in packed registers: component .x belongs to the lane's closest-hit ray,
+// .y to its pending shadow ray.  One v_pk_* instruction then advances both Moeller-Trumbore chains
+// (this is how CDNA reaches its fp32 peak), with the triangle in SGPRs broadcast to both halves.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct RayPair {
+  v2f ox, oy, oz, dx, dy, dz;
+};
+struct TriS {  // one triangle held in scalars
+  float p0x, p0y, p0z, e0x, e0y, e0z, e1x, e1y, e1z;
+};
+struct MTPair {
+  v2f det, t, u, v;
+};
+DMT_DEV MTPair mt_pair(TriS const& T, RayPair const& r) {  // same operation order as mt_test
+  v2f const cx = r.dy * T.e1z - r.dz * T.e1y;
+  v2f const cy = r.dz * T.e1x - r.dx * T.e1z;
+  v2f const cz = r.dx * T.e1y - r.dy * T.e1x;
+  MTPair m;
+  m.det = cx * T.e0x + cy * T.e0y + cz * T.e0z;
+  v2f inv;
+  inv.x = __builtin_amdgcn_rcpf(m.det.x);
+  inv.y = __builtin_amdgcn_rcpf(m.det.y);
+  v2f const ovx = r.ox - T.p0x, ovy = r.oy - T.p0y, ovz = r.oz - T.p0z;
+  v2f const qx = ovy * T.e0z - ovz * T.e0y;
+  v2f const qy = ovz * T.e0x - ovx * T.e0z;
+  v2f const qz = ovx * T.e0y - ovy * T.e0x;
+  m.u = inv * (cx * ovx + cy * ovy + cz * ovz);
+  m.v = inv * (qx * r.dx + qy * r.dy + qz * r.dz);
+  m.t = inv * (qx * T.e1x + qy * T.e1y + qz * T.e1z);
+  return m;
+}
+DMT_DEV bool mt_valid(float det, float t, float u, float v) {  // shapes.cu:19,35-38
+  float const tol = 1e-7f;
+  return !(fabsf(det) < tol) && (u >= -tol && v >= -tol && (u + v) <= 1 + tol) && (t > 1e-4f);
 }
 
 struct Hit {
