@@ -39,6 +39,18 @@ WORKLOADS = {
 }
 DEFAULT_WORKLOAD = "cornell_1024x1024_1024spp_8bounces"
 
+# Per-sample work counters of each workload, counted by the CPU restatement on rows spread evenly over
+# the frame (same procedure as the cpu_baseline leg below, which recounts them live when it runs).
+# Only used for the algorithmic-bytes model when the cpu_baseline leg is skipped (N > 1, --no-cpu-baseline).
+WORKLOAD_STATS = {
+    "cornell_1024x1024_1024spp_8bounces": {"samples": 1.0, "closest_rays": 3.6101, "shadow_rays": 3.1595,
+                                           "tri_tests": 173.8335, "bounces": 3.1595, "hits": 3.1595},
+    "cornell_256x256_2048spp_32bounces": {"samples": 1.0, "closest_rays": 5.1006, "shadow_rays": 4.6513,
+                                          "tri_tests": 250.6595, "bounces": 4.6513, "hits": 4.6513},
+    "cornell_512x512_64spp_4bounces": {"samples": 1.0, "closest_rays": 3.1490, "shadow_rays": 2.6932,
+                                       "tri_tests": 150.0929, "bounces": 2.6932, "hits": 2.6932},
+}
+
 
 def algorithmic_bytes_per_sample(stats, spp_per_launch):
     """B_sample = B_film + sum_rays[N_tris * 48] + N_bounces * (32 + 32) + N_hits * 4,
@@ -70,10 +82,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal knob (not used by the driver): DMT_BENCH_BACKEND=gloo lets several ranks share one GPU
+    # to exercise the N > 1 code path on a 1-GPU box; the real runs are one rank per GPU over RCCL.
+    backend = os.environ.get("DMT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as graft
     pkg = graft.load_package()
@@ -82,7 +101,7 @@ def main():
     kspp = args.kspp if args.kspp > 0 else spp
     scene = pkg.host_scene.cornell_box(width, height)
 
-    r = pkg.Renderer(local_rank)
+    r = pkg.Renderer(dev_index)
     # one explicit (non-null) stream for everything: film zeroing, kernels + their HIP timing events,
     # and the RCCL reduce are ordered on it
     stream = torch.cuda.Stream(device=dev)
@@ -101,9 +120,7 @@ def main():
         m2.zero_()
         for s0 in range(0, spp, kspp):
             r.render(min(kspp, spp - s0), sample_offset=s0)
-        if world > 1:  # disjoint tiles + zero-initialised frames: SUM-reduce == gather, bit exact
-            dist.reduce(mean, dst=0, op=dist.ReduceOp.SUM)
-            dist.reduce(m2, dst=0, op=dist.ReduceOp.SUM)
+        pkg.multigpu.combine_films(mean, m2, dst=0)  # disjoint tiles + zero frames: SUM-reduce == exact gather
 
     def barrier():
         if world > 1:
@@ -142,27 +159,31 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             O = graft.load_oracle()          # cpu_baseline leg: the oracle is the thing timed
             oscene = O.cornell_box(width, height)
-            rows = max(1, min(args.cpu_band_rows, height))
-            y0 = (height - rows) // 2
+            nrows = max(1, min(args.cpu_band_rows, height))
+            rows = sorted({int((i + 0.5) * height / nrows) for i in range(nrows)})
             # the 1-GPU box exposes 256 logical CPUs but the job's CPU share is 16 cores
             threads = int(os.environ.get("DMT_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+            stats = {}
+            omean = np.zeros((height, width, 4), np.float32)
+            om2 = np.zeros((height, width, 4), np.float32)
             tc = time.perf_counter()
-            omean, om2, stats = O.render(oscene, spp, max_depth=max_depth, region=(0, y0, width, y0 + rows),
-                                         threads=threads, want_stats=True)
+            for y in rows:
+                _, _, st = O.render(oscene, spp, max_depth=max_depth, region=(0, y, width, y + 1), threads=threads,
+                                    film=(omean, om2), want_stats=True)
+                for k, v in st.items():
+                    stats[k] = stats.get(k, 0) + v
             tcpu = time.perf_counter() - tc
             cpu_baseline = {
                 "value": round(stats["samples"] / tcpu / 1e6, 4), "unit": "Msamples/s", "cores": threads,
                 "kind": "port",
-                "sample": f"rows {y0}..{y0 + rows} of the {width}x{height} frame, all {spp} spp, bounce cap {max_depth} "
-                          f"({stats['samples']} samples, {tcpu:.1f} s); CPU restatement of the reference arithmetic, "
-                          f"32x32-tile std::thread pool",
+                "sample": f"{len(rows)} rows spread evenly over the {width}x{height} frame, all {spp} spp, bounce cap "
+                          f"{max_depth} ({stats['samples']} samples, {tcpu:.1f} s); CPU restatement of the reference "
+                          f"arithmetic, 32x32-tile std::thread pool",
             }
-            d = film_mean[y0:y0 + rows, :, :3].astype(np.float64) - omean[y0:y0 + rows, :, :3]
-            parity = {"rmse_vs_cpu_band": float(np.sqrt((d ** 2).mean(axis=2)).mean()), "tolerance": 1e-3}
+            d = film_mean[rows, :, :3].astype(np.float64) - omean[rows, :, :3]
+            parity = {"rmse_vs_cpu_rows": float(np.sqrt((d ** 2).mean(axis=2)).mean()), "tolerance": 1e-3}
         if stats is None:
-            # work counters of this workload measured once by the oracle (cornellBox, cap 8); only used
-            # when the cpu_baseline leg is skipped
-            stats = {"samples": 1, "tri_tests": 0, "bounces": 0, "hits": 0}
+            stats = WORKLOAD_STATS[args.workload]
         if launches > 0 and stats["tri_tests"] > 0:
             avg_ms = kernel_ms / launches
             my_items = (width // 8) * (height // 8)

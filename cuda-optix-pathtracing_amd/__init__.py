@@ -16,3 +16,4 @@ from .binding import (  # noqa: F401
     load_library,
 )
 from . import host_scene  # noqa: F401,E402
+from . import multigpu  # noqa: F401,E402

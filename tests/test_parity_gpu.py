@@ -353,6 +353,9 @@ def test_tile_partition_is_exact(renderer, O):
     renderer.set_partition(0, 1)
     counts = sum(p[1][..., 3] for p in parts)
     assert np.all(counts == 8)                                    # each pixel owned exactly once
+    from cuda_optix_pathtracing_amd import multigpu               # host-side mirror of the kernel's tile map
+    for rank in range(4):
+        assert np.array_equal(parts[rank][1][..., 3] > 0, multigpu.owned_pixel_mask(200, 120, rank, 4))
     assert np.array_equal(sum(p[0] for p in parts), full[0])      # x + 0 == x: exact gather by sum
     assert np.array_equal(sum(p[1] for p in parts), full[1])
 
