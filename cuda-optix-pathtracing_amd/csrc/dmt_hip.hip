@@ -229,6 +229,38 @@ DMT_DEV void lane_step(SceneView const& sc, int maxDepth, PathState& st, Sink&& 
 
 // running film statistics of the lane's pixel, in LDS as [field][thread]: touched once per sample
 __shared__ float s_film[7 * kLdsThreads];
+// the lane's NEXT sample, prepared ahead of need (sampler values + camera ray), [field][thread]
+__shared__ float s_prep[14 * kLdsThreads];
+
+// Starting a sample costs ~2k instructions (8 scrambled radical inverses + camera ray).  Paths end at
+// different times, so doing it on demand would run that code for a handful of lanes on almost every
+// pass.  Instead every lane keeps its next sample PREPARED in LDS; a finished lane swaps it in (a few
+// LDS moves) and the preparation of the following one is batched: it runs when at least half the wave
+// needs one, or when some lane would otherwise starve.  Sample values are pure functions of
+// (pixel, sample), so preparing early changes nothing.
+DMT_DEV void prepare_sample(CameraXf const& cam, SamplerParams const& sp, int px, int py, int32_t pixBase,
+                            uint32_t s) {
+  float* const prep = s_prep + threadIdx.x;
+  int32_t const hidx = pixBase + int32_t(s) * (sp.scale0 * sp.scale1);
+  sampler_values(uint32_t(hidx), prep);
+  Ray const r = camera_ray(cam, sp, px, py, hidx);
+  prep[8 * kLdsThreads] = r.o.x, prep[9 * kLdsThreads] = r.o.y, prep[10 * kLdsThreads] = r.o.z;
+  prep[11 * kLdsThreads] = r.d.x, prep[12 * kLdsThreads] = r.d.y, prep[13 * kLdsThreads] = r.d.z;
+}
+DMT_DEV void path_begin_prepared(PathState& st) {
+  float const* const prep = s_prep + threadIdx.x;
+  float* const u = s_sampler_u + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) u[k * kLdsThreads] = prep[k * kLdsThreads];
+  set_ray(st, mk3(prep[8 * kLdsThreads], prep[9 * kLdsThreads], prep[10 * kLdsThreads]),
+          mk3(prep[11 * kLdsThreads], prep[12 * kLdsThreads], prep[13 * kLdsThreads]));
+  st.rng.dim = 2;
+  st.beta = mk3(1, 1, 1);
+  st.L = mk3(0, 0, 0);
+  st.depth = 0;
+  st.lastT = false;
+  st.active = true;
+}
 
 __global__ void __launch_bounds__(256) k_megakernel(RenderParams P) {
   int const lane = int(threadIdx.x) & 63;
@@ -273,8 +305,17 @@ __global__ void __launch_bounds__(256) k_megakernel(RenderParams P) {
       film[3 * kLdsThreads] = M2.x, film[4 * kLdsThreads] = M2.y, film[5 * kLdsThreads] = M2.z;
       film[6 * kLdsThreads] = N;
     };
+    uint32_t sPrep = P.sampleOffset;  // samples [sampleOffset, sPrep) have been prepared; sNext <= sPrep <= sNext + 1
     for (;;) {
-      if (!st.active && sNext < sEnd) path_begin(st, P.cam, P.sp, px, py, pixBase, sNext++);
+      bool const needPrep = sPrep == sNext && sPrep < sEnd;
+      bool const starving = !st.active && needPrep;
+      if (__any(starving) || __popcll(__ballot(needPrep)) >= 32) {
+        if (needPrep) prepare_sample(P.cam, P.sp, px, py, pixBase, sPrep++);
+      }
+      if (!st.active && sNext < sPrep) {
+        path_begin_prepared(st);
+        ++sNext;
+      }
       if (!__any(st.active || st.hasShadow)) break;
       lane_step(P.scene, P.maxDepth, st, welford);
     }

@@ -287,6 +287,18 @@ DMT_DEV int32_t halton_pixel_base(SamplerParams const& p, int px, int py) {
 constexpr int kLdsThreads = 256;  // threads per block of every kernel that traces paths
 __shared__ float s_sampler_u[8 * kLdsThreads];
 
+// the 8 values of Halton index `haltonIndex` into column u[k * kLdsThreads], k = 0..7
+DMT_DEV void sampler_values(uint32_t haltonIndex, float* u) {
+  u[0 * kLdsThreads] = sample_dim<2, 5>(haltonIndex);
+  u[1 * kLdsThreads] = sample_dim<3, 7>(haltonIndex);
+  u[2 * kLdsThreads] = sample_dim<4, 11>(haltonIndex);
+  u[3 * kLdsThreads] = sample_dim<5, 13>(haltonIndex);
+  u[4 * kLdsThreads] = sample_dim<6, 17>(haltonIndex);
+  u[5 * kLdsThreads] = sample_dim<7, 19>(haltonIndex);
+  u[6 * kLdsThreads] = sample_dim<8, 23>(haltonIndex);
+  u[7 * kLdsThreads] = sample_dim<9, 29>(haltonIndex);
+}
+
 struct Sampler {
   int dim;
 
