@@ -18,7 +18,10 @@ class DmtError(RuntimeError):
 
 
 def library_path():
-    return _CSRC / "libdmt_hip.so"
+    # DMT_HIP_LIB: developer knob to A/B an experimental build of the same C ABI
+    import os
+    alt = os.environ.get("DMT_HIP_LIB")
+    return Path(alt) if alt else _CSRC / "libdmt_hip.so"
 
 
 def build_library(force=False):

@@ -62,10 +62,27 @@ struct PathState {
   bool hasShadow;   // shadow ray / smax / C valid
   bool finPending;  // the pending shadow ray belongs to the finished sample parked in Lfin
   float smax;
-  f3 C;
-  f3 Lfin;
   Sampler rng;
 };
+// cold per-lane values in LDS, [field][thread]: pending NEE contribution C (0..2) and the parked
+// radiance Lfin of a finished sample (3..5); each is touched once per ray pass at most
+__shared__ float s_cold[6 * kLdsThreads];
+DMT_DEV void put_C(f3 v) {
+  float* const c = s_cold + threadIdx.x;
+  c[0 * kLdsThreads] = v.x, c[1 * kLdsThreads] = v.y, c[2 * kLdsThreads] = v.z;
+}
+DMT_DEV f3 get_C() {
+  float const* const c = s_cold + threadIdx.x;
+  return mk3(c[0 * kLdsThreads], c[1 * kLdsThreads], c[2 * kLdsThreads]);
+}
+DMT_DEV void put_Lfin(f3 v) {
+  float* const c = s_cold + threadIdx.x;
+  c[3 * kLdsThreads] = v.x, c[4 * kLdsThreads] = v.y, c[5 * kLdsThreads] = v.z;
+}
+DMT_DEV f3 get_Lfin() {
+  float const* const c = s_cold + threadIdx.x;
+  return mk3(c[3 * kLdsThreads], c[4 * kLdsThreads], c[5 * kLdsThreads]);
+}
 DMT_DEV f3 ray_dir(PathState const& st) { return mk3(st.rp.dx.x, st.rp.dy.x, st.rp.dz.x); }
 DMT_DEV void set_ray(PathState& st, f3 o, f3 d) {
   st.rp.ox.x = o.x, st.rp.oy.x = o.y, st.rp.oz.x = o.z;
@@ -124,10 +141,10 @@ DMT_DEV bool path_shade(SceneView const& sc, int maxDepth, PathState& st, int be
       if (!is_zero(f)) {
         f3 const Le = eval_light(light, ls);
         if (ls.delta) {
-          st.C = st.beta * Le * f / pmf;
+          put_C(st.beta * Le * f / pmf);
         } else {  // power heuristic, no division by the light pdf (:233-238)
           float const w = sqr(pmf * ls.pdf) / sqr(pmf * ls.pdf + bsdfPdf);
-          st.C = Le * f * st.beta * w;
+          put_C(Le * f * st.beta * w);
         }
         set_shadow_ray(st, offset_ray_origin(hit.pos, hit.error, hit.normal, ls.direction), ls.direction);
         st.smax = ls.distance;
@@ -207,18 +224,19 @@ DMT_DEV void lane_step(SceneView const& sc, int maxDepth, PathState& st, Sink&& 
   if (doS) {
     st.hasShadow = false;
     if (st.finPending) {  // the shadow ray of an already finished sample
-      if (!occluded) st.Lfin = st.Lfin + st.C;
+      f3 Lfin = get_Lfin();
+      if (!occluded) Lfin = Lfin + get_C();
       st.finPending = false;
-      sink(st.Lfin);
+      sink(Lfin);
     } else if (!occluded) {
-      st.L = st.L + st.C;  // NEE of the previous bounce, added before anything of this bounce
+      st.L = st.L + get_C();  // NEE of the previous bounce, added before anything of this bounce
     }
   }
   if (doC) {
     if (path_shade(sc, maxDepth, st, bestTri, bu, bv)) {
       st.active = false;
       if (st.hasShadow) {  // last NEE still untraced: park the sample, the lane may start the next
-        st.Lfin = st.L;
+        put_Lfin(st.L);
         st.finPending = true;
       } else {
         sink(st.L);
@@ -262,7 +280,13 @@ DMT_DEV void path_begin_prepared(PathState& st) {
   st.active = true;
 }
 
-__global__ void __launch_bounds__(256) k_megakernel(RenderParams P) {
+#ifndef DMT_MIN_WAVES_PER_SIMD
+#define DMT_MIN_WAVES_PER_SIMD 4
+#endif
+#ifndef DMT_PREP_THRESHOLD
+#define DMT_PREP_THRESHOLD 64
+#endif
+__global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD) k_megakernel(RenderParams P) {
   int const lane = int(threadIdx.x) & 63;
   float* const film = s_film + threadIdx.x;
   for (;;) {
@@ -309,7 +333,7 @@ __global__ void __launch_bounds__(256) k_megakernel(RenderParams P) {
     for (;;) {
       bool const needPrep = sPrep == sNext && sPrep < sEnd;
       bool const starving = !st.active && needPrep;
-      if (__any(starving) || __popcll(__ballot(needPrep)) >= 32) {
+      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) {
         if (needPrep) prepare_sample(P.cam, P.sp, px, py, pixBase, sPrep++);
       }
       if (!st.active && sNext < sPrep) {
@@ -356,7 +380,7 @@ __global__ void k_test_trace_log(SceneView sc, CameraXf cam, SamplerParams sp, i
     bool occluded;
     trace_pair_brute(sc, st, doC, doS, bestTri, bu, bv, occluded);
     if (doS) {
-      if (!occluded) st.L = st.L + st.C;
+      if (!occluded) st.L = st.L + get_C();
       st.hasShadow = false;
     }
     bool ended = true;
