@@ -11,6 +11,7 @@ The directory name contains a hyphen, so import it through ``__graft_entry__.loa
 from .binding import (  # noqa: F401
     DmtError,
     Renderer,
+    bvh_validate,
     build_library,
     library_path,
     load_library,

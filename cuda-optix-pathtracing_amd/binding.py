@@ -53,7 +53,7 @@ EXPORTED_SYMBOLS = [
     "dmt_ctx_create", "dmt_ctx_destroy", "dmt_last_error", "dmt_upload_triangles", "dmt_upload_bsdfs",
     "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_partition",
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
-    "dmt_render", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_test_triangle_intersect",
+    "dmt_render", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
     "dmt_test_sampler", "dmt_test_camera_rays", "dmt_test_bsdf", "dmt_test_light", "dmt_test_half",
     "dmt_test_trace_samples", "dmt_test_trace_log", "dmt_test_closest_hit",
 ]
@@ -70,6 +70,16 @@ def _f32(a, shape=None):
 
 def _i32(a):
     return np.ascontiguousarray(a, np.int32).reshape(-1)
+
+
+def bvh_validate(xs, ys, zs):
+    """Host-only BVH build + invariant check; returns dict(node_count, depth, max_leaf, ok)."""
+    lib = load_library()
+    xs, ys, zs = _f32(xs), _f32(ys), _f32(zs)
+    n = xs.size // 4
+    nc, d, ml = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.dmt_bvh_validate(_p(xs), _p(ys), _p(zs), C.c_size_t(n), C.byref(nc), C.byref(d), C.byref(ml))
+    return {"ok": rc == 0, "node_count": nc.value, "depth": d.value, "max_leaf": ml.value}
 
 
 class Renderer:

@@ -27,6 +27,7 @@
 
 #include "../../include/dmt_hip.h"
 #include "pt_device.hpp"
+#include "bvh_device.hpp"
 
 using namespace dmt;
 
@@ -34,6 +35,7 @@ namespace {
 
 struct RenderParams {
   SceneView scene;
+  BvhView bvh;
   CameraXf cam;
   SamplerParams sp;
   float4* __restrict__ mean;
@@ -211,16 +213,31 @@ DMT_DEV void trace_pair_brute(SceneView const& sc, PathState const& st, bool doC
   }
 }
 
+// BVH flavour of the pass: closest-hit traversal for the path ray, then any-hit traversal for the
+// pending shadow ray.  Results are identical to trace_pair_brute (same triangle test, same tie rule).
+DMT_DEV void trace_pair_bvh(BvhView const& bvh, PathState const& st, bool doC, bool doS, uint32_t gtid,
+                            int& bestTri, float& bu, float& bv, bool& occluded) {
+  float bt;
+  bvh_closest(bvh, doC, mk3(st.rp.ox.x, st.rp.oy.x, st.rp.oz.x), mk3(st.rp.dx.x, st.rp.dy.x, st.rp.dz.x), gtid,
+              bestTri, bt, bu, bv);
+  occluded = bvh_any(bvh, doS, mk3(st.rp.ox.y, st.rp.oy.y, st.rp.oz.y), mk3(st.rp.dx.y, st.rp.dy.y, st.rp.dz.y),
+                     st.smax, gtid);
+}
+
 // One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
 // sink(L) is called once per completed sample, in sample order.
-template <class Sink>
-DMT_DEV void lane_step(SceneView const& sc, int maxDepth, PathState& st, Sink&& sink) {
+template <bool BVH, class Sink>
+DMT_DEV void lane_step(SceneView const& sc, BvhView const& bvh, uint32_t gtid, int maxDepth, PathState& st,
+                       Sink&& sink) {
   bool const doC = st.active;
   bool const doS = st.hasShadow;
   int bestTri;
   float bu, bv;
   bool occluded;
-  trace_pair_brute(sc, st, doC, doS, bestTri, bu, bv, occluded);
+  if constexpr (BVH)
+    trace_pair_bvh(bvh, st, doC, doS, gtid, bestTri, bu, bv, occluded);
+  else
+    trace_pair_brute(sc, st, doC, doS, bestTri, bu, bv, occluded);
   if (doS) {
     st.hasShadow = false;
     if (st.finPending) {  // the shadow ray of an already finished sample
@@ -283,11 +300,16 @@ DMT_DEV void path_begin_prepared(PathState& st) {
 #ifndef DMT_MIN_WAVES_PER_SIMD
 #define DMT_MIN_WAVES_PER_SIMD 4
 #endif
+#ifndef DMT_MIN_WAVES_PER_SIMD_BVH
+#define DMT_MIN_WAVES_PER_SIMD_BVH 3
+#endif
 #ifndef DMT_PREP_THRESHOLD
 #define DMT_PREP_THRESHOLD 64
 #endif
-__global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD) k_megakernel(RenderParams P) {
+template <bool BVH>
+DMT_DEV void megakernel_body(RenderParams const& P) {
   int const lane = int(threadIdx.x) & 63;
+  uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
   float* const film = s_film + threadIdx.x;
   for (;;) {
     uint32_t item = 0;
@@ -341,7 +363,7 @@ __global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD) k_megakernel(Rend
         ++sNext;
       }
       if (!__any(st.active || st.hasShadow)) break;
-      lane_step(P.scene, P.maxDepth, st, welford);
+      lane_step<BVH>(P.scene, P.bvh, gtid, P.maxDepth, st, welford);
     }
     if (inside) {  // endSample, megakernel.cuh:81-85
       P.mean[pidx] = make_float4(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads], 0.f);
@@ -351,18 +373,27 @@ __global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD) k_megakernel(Rend
   }
 }
 
+// brute force: the reference's semantics, every triangle tested (small scenes, parity mode)
+__global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD) k_megakernel(RenderParams P) { megakernel_body<false>(P); }
+// BVH traversal (large scenes); 16 KB more LDS per block for the traversal stacks
+__global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD_BVH) k_megakernel_bvh(RenderParams P) { megakernel_body<true>(P); }
+
 // ---------------------------------------------------------------------------------------------
 // device unit-test kernels
 // ---------------------------------------------------------------------------------------------
-__global__ void k_test_trace(SceneView sc, CameraXf cam, SamplerParams sp, int maxDepth, int n,
-                             int32_t const* pxs, int32_t const* pys, int32_t const* ss, float* L3) {
+__global__ void k_test_trace(SceneView sc, BvhView bvh, bool useBvh, CameraXf cam, SamplerParams sp, int maxDepth,
+                             int n, int32_t const* pxs, int32_t const* pys, int32_t const* ss, float* L3) {
   int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
   PathState st{};
   if (i < n) path_begin(st, cam, sp, pxs[i], pys[i], halton_pixel_base(sp, pxs[i], pys[i]), uint32_t(ss[i]));
   auto store = [&](f3 L) { L3[3 * i] = L.x, L3[3 * i + 1] = L.y, L3[3 * i + 2] = L.z; };
+  uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
   for (;;) {
     if (!__any(st.active || st.hasShadow)) break;
-    lane_step(sc, maxDepth, st, store);
+    if (useBvh)
+      lane_step<true>(sc, bvh, gtid, maxDepth, st, store);
+    else
+      lane_step<false>(sc, bvh, gtid, maxDepth, st, store);
   }
 }
 
@@ -499,8 +530,8 @@ __global__ void k_test_half(int n, float const* fin, uint16_t* hout, uint16_t co
   if (hin && fout) fout[i] = h2f(hin[i]);
 }
 
-__global__ void k_test_closest(SceneView sc, int n, float const* o3, float const* d3, int32_t* tri,
-                               float* tOut) {
+__global__ void k_test_closest(SceneView sc, BvhView bvh, bool useBvh, int n, float const* o3, float const* d3,
+                               int32_t* tri, float* tOut) {
   int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
   bool const alive = i < n;
   PathState st{};
@@ -510,8 +541,11 @@ __global__ void k_test_closest(SceneView sc, int n, float const* o3, float const
   int best;
   float bu, bv, bt = kInf;
   bool occluded;
-  trace_pair_brute(sc, st, alive, false, best, bu, bv, occluded);
-  if (alive && best >= 0) {  // t of the winning triangle (same arithmetic as the loop)
+  if (useBvh)
+    trace_pair_bvh(bvh, st, alive, false, blockIdx.x * blockDim.x + threadIdx.x, best, bu, bv, occluded);
+  else
+    trace_pair_brute(sc, st, alive, false, best, bu, bv, occluded);
+  if (alive && best >= 0) {  // t of the winning triangle (same arithmetic as the loops)
     TriS const T = load_tri(to_const_as(sc.tris), uint32_t(best));
     bt = mt_pair(T, st.rp).t.x;
   }
@@ -536,6 +570,17 @@ struct dmt_ctx {
   Rec32* d_inf = nullptr;
   uint32_t triCount = 0, bsdfCount = 0, lightCount = 0, infCount = 0;
   uint32_t maxMatId = 0;
+  // BVH (built on demand for DMT_ACCEL_BVH)
+  std::vector<float> h_xs, h_ys, h_zs;  // host copy of the soup (the builder's input)
+  std::vector<uint32_t> h_mat;
+  Bvh4Node* d_bvhNodes = nullptr;
+  TriIsect* d_trisBvh = nullptr;
+  uint32_t* d_overflow = nullptr;
+  size_t overflowThreads = 0;
+  bool haveBvh = false;
+  int bvhDepth = 0;
+  uint32_t bvhNodeCount = 0;
+  int blocksPerCUBvh = 0;
   bool haveTris = false, haveBsdfs = false, haveLights = false, haveCamera = false;
   // camera
   dmt_camera cam{};
@@ -645,6 +690,13 @@ SceneView sceneView(dmt_ctx const* c) {
   return s;
 }
 
+BvhView bvhView(dmt_ctx const* c, size_t threads) {
+  BvhView b;
+  b.nodes = c->d_bvhNodes, b.tris = c->d_trisBvh, b.overflow = c->d_overflow;
+  b.overflowStride = uint32_t(threads);
+  return b;
+}
+
 template <class T>
 int devAlloc(dmt_ctx* ctx, T** p, size_t n) {
   if (*p) {
@@ -653,6 +705,43 @@ int devAlloc(dmt_ctx* ctx, T** p, size_t n) {
   }
   if (n == 0) n = 1;
   HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return DMT_OK;
+}
+
+int ensureOverflow(dmt_ctx* ctx, size_t threads) {
+  if (threads <= ctx->overflowThreads && ctx->d_overflow) return DMT_OK;
+  if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
+  ctx->d_overflow = nullptr, ctx->overflowThreads = 0;
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_overflow), threads * size_t(kBvhOverflowStack) * sizeof(uint32_t)));
+  ctx->overflowThreads = threads;
+  return DMT_OK;
+}
+
+// (re)build the 4-wide BVH of the uploaded soup and upload nodes + slot-ordered triangle records
+int buildBvh(dmt_ctx* ctx) {
+  uint32_t const n = ctx->triCount;
+  bvh_build::Result const r = bvh_build::build(ctx->h_xs.data(), ctx->h_ys.data(), ctx->h_zs.data(), n);
+  std::vector<TriIsect> slots(n);
+  for (uint32_t s = 0; s < n; ++s) {
+    uint32_t const i = r.slotToTri[s];
+    float const* xs = &ctx->h_xs[4 * size_t(i)];
+    float const* ys = &ctx->h_ys[4 * size_t(i)];
+    float const* zs = &ctx->h_zs[4 * size_t(i)];
+    TriIsect& t = slots[s];
+    t.p0x = xs[0], t.p0y = ys[0], t.p0z = zs[0];
+    t.e0x = xs[1] - xs[0], t.e0y = ys[1] - ys[0], t.e0z = zs[1] - zs[0];
+    t.e1x = xs[2] - xs[0], t.e1y = ys[2] - ys[0], t.e1z = zs[2] - zs[0];
+    t.matId = ctx->h_mat[i], t.pad0 = i, t.pad1 = 0;
+  }
+  int rc = devAlloc(ctx, &ctx->d_bvhNodes, r.nodes.size());
+  if (rc) return rc;
+  rc = devAlloc(ctx, &ctx->d_trisBvh, size_t(n));
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(ctx->d_bvhNodes, r.nodes.data(), r.nodes.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice));
+  if (n) HIP_TRY(ctx, hipMemcpy(ctx->d_trisBvh, slots.data(), size_t(n) * sizeof(TriIsect), hipMemcpyHostToDevice));
+  ctx->bvhDepth = r.depth;
+  ctx->bvhNodeCount = uint32_t(r.nodes.size());
+  ctx->haveBvh = true;
   return DMT_OK;
 }
 
@@ -709,6 +798,9 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
   int bpc = 0;
   if (e == hipSuccess)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, reinterpret_cast<void const*>(k_megakernel), 256, 0);
+  int bpcBvh = 0;
+  if (e == hipSuccess)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpcBvh, reinterpret_cast<void const*>(k_megakernel_bvh), 256, 0);
   if (e != hipSuccess) {
     g_createError = std::string("dmt_ctx_create: ") + hipGetErrorString(e);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -718,6 +810,7 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
   ctx->stream = ctx->ownStream;
   ctx->cuCount = prop.multiProcessorCount;
   ctx->blocksPerCU = bpc > 0 ? bpc : 1;
+  ctx->blocksPerCUBvh = bpcBvh > 0 ? bpcBvh : 1;
   *out = ctx;
   return DMT_OK;
 }
@@ -736,6 +829,9 @@ int dmt_ctx_destroy(dmt_ctx* ctx) {
   (void)hipFree(ctx->d_lights);
   (void)hipFree(ctx->d_inf);
   (void)hipFree(ctx->d_counter);
+  (void)hipFree(ctx->d_bvhNodes);
+  (void)hipFree(ctx->d_trisBvh);
+  (void)hipFree(ctx->d_overflow);
   if (ctx->ownFilm) {
     (void)hipFree(ctx->d_mean);
     (void)hipFree(ctx->d_m2);
@@ -787,6 +883,10 @@ int dmt_upload_triangles(dmt_ctx* ctx, const float* xs, const float* ys, const f
   ctx->triCount = uint32_t(count);
   ctx->maxMatId = maxMat;
   ctx->haveTris = true;
+  ctx->h_xs.assign(xs, xs + 4 * count), ctx->h_ys.assign(ys, ys + 4 * count), ctx->h_zs.assign(zs, zs + 4 * count);
+  ctx->h_mat.assign(mat_id, mat_id + count);
+  ctx->haveBvh = false;
+  if (ctx->accel == DMT_ACCEL_BVH) return buildBvh(ctx);
   return DMT_OK;
 }
 
@@ -861,9 +961,12 @@ int dmt_set_limits(dmt_ctx* ctx, int max_depth) {
 
 int dmt_set_accel(dmt_ctx* ctx, int mode) {
   if (!ctx) return DMT_ERR_INVALID;
-  if (mode != DMT_ACCEL_BRUTE_FORCE)
-    return fail(ctx, DMT_ERR_INVALID, "dmt_set_accel: only DMT_ACCEL_BRUTE_FORCE is built in this revision");
+  if (mode != DMT_ACCEL_BRUTE_FORCE && mode != DMT_ACCEL_BVH) return fail(ctx, DMT_ERR_INVALID, "dmt_set_accel: unknown mode");
   ctx->accel = mode;
+  if (mode == DMT_ACCEL_BVH && ctx->haveTris && !ctx->haveBvh) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return buildBvh(ctx);
+  }
   return DMT_OK;
 }
 
@@ -958,8 +1061,9 @@ int dmt_render(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y
   P.maxDepth = ctx->maxDepth;
   if (P.numItems == 0) return DMT_OK;
 
+  bool const useBvh = ctx->accel == DMT_ACCEL_BVH;
   uint32_t const wavesWanted = P.numItems;
-  uint32_t blocks = uint32_t(ctx->cuCount) * uint32_t(ctx->blocksPerCU);
+  uint32_t blocks = uint32_t(ctx->cuCount) * uint32_t(useBvh ? ctx->blocksPerCUBvh : ctx->blocksPerCU);
   uint32_t const blocksNeeded = (wavesWanted + 3) / 4;
   if (blocks > blocksNeeded) blocks = blocksNeeded;
   if (blocks == 0) blocks = 1;
@@ -973,11 +1077,69 @@ int dmt_render(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y
   auto& ev = ctx->events[ctx->eventsUsed];
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
-  hipLaunchKernelGGL(k_megakernel, dim3(blocks), dim3(256), 0, ctx->stream, P);
+  if (useBvh) {
+    if (!ctx->haveBvh) return fail(ctx, DMT_ERR_STATE, "dmt_render: BVH not built");
+    int const rcO = ensureOverflow(ctx, size_t(ctx->cuCount) * size_t(ctx->blocksPerCUBvh) * 256);
+    if (rcO) return rcO;
+    P.bvh = bvhView(ctx, size_t(blocks) * 256);
+    hipLaunchKernelGGL(k_megakernel_bvh, dim3(blocks), dim3(256), 0, ctx->stream, P);
+  } else {
+    hipLaunchKernelGGL(k_megakernel, dim3(blocks), dim3(256), 0, ctx->stream, P);
+  }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
   ++ctx->eventsUsed;
   return DMT_OK;
+}
+
+// Host-only: build the BVH of a soup and check its invariants (every triangle in exactly one leaf,
+// every child box encloses all vertices below it, depth within the traversal-stack bound).
+int dmt_bvh_validate(const float* xs, const float* ys, const float* zs, size_t count, int* node_count, int* depth,
+                     int* max_leaf) {
+  if ((count && (!xs || !ys || !zs)) || count > 0x0FFFFFFFu) return DMT_ERR_INVALID;
+  bvh_build::Result const r = bvh_build::build(xs, ys, zs, uint32_t(count));
+  if (node_count) *node_count = int(r.nodes.size());
+  if (depth) *depth = r.depth;
+  std::vector<uint8_t> seen(count, 0);
+  int maxLeaf = 0;
+  bool ok = r.depth <= kBvhMaxDepth;
+  // recursive containment check, explicit stack: (node, box of the parent slot)
+  struct Item {
+    uint32_t ref;
+    float lo[3], hi[3];
+  };
+  std::vector<Item> stack;
+  float const inf = std::numeric_limits<float>::infinity();
+  stack.push_back({0u, {-inf, -inf, -inf}, {inf, inf, inf}});
+  while (!stack.empty() && ok) {
+    Item const it = stack.back();
+    stack.pop_back();
+    if (it.ref & kBvhLeafFlag) {
+      uint32_t const first = it.ref & 0x0FFFFFFFu, cnt = ((it.ref >> 28) & 7u) + 1u;
+      maxLeaf = std::max(maxLeaf, int(cnt));
+      for (uint32_t s = first; s < first + cnt && ok; ++s) {
+        if (s >= count) { ok = false; break; }
+        uint32_t const t = r.slotToTri[s];
+        if (t >= count || seen[t]++) ok = false;
+        for (int v = 0; v < 3 && ok; ++v) {
+          float const p[3] = {xs[4 * size_t(t) + v], ys[4 * size_t(t) + v], zs[4 * size_t(t) + v]};
+          for (int a = 0; a < 3; ++a) ok = ok && p[a] >= it.lo[a] && p[a] <= it.hi[a];
+        }
+      }
+      continue;
+    }
+    if (it.ref >= r.nodes.size()) { ok = false; break; }
+    Bvh4Node const& n = r.nodes[it.ref];
+    for (int k = 0; k < 4; ++k) {
+      if (n.child[k] == kBvhEmpty) continue;
+      Item c{n.child[k], {n.minx[k], n.miny[k], n.minz[k]}, {n.maxx[k], n.maxy[k], n.maxz[k]}};
+      for (int a = 0; a < 3; ++a) ok = ok && c.lo[a] >= it.lo[a] && c.hi[a] <= it.hi[a];  // nested boxes
+      stack.push_back(c);
+    }
+  }
+  for (size_t i = 0; i < count && ok; ++i) ok = seen[i] == 1;
+  if (max_leaf) *max_leaf = maxLeaf;
+  return ok && maxLeaf <= kBvhMaxLeafTris ? DMT_OK : DMT_ERR_STATE;
 }
 
 int dmt_sync(dmt_ctx* ctx) {
@@ -1176,8 +1338,15 @@ int dmt_test_trace_samples(dmt_ctx* ctx, int n, const int32_t* pxs, const int32_
   int32_t* dss = S.up(ss, size_t(n));
   float* dL = S.up<float>(nullptr, 3 * size_t(n));
   SCRATCH_CHECK(ctx, dpx && dpy && dss && dL);
-  hipLaunchKernelGGL(k_test_trace, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, sceneView(ctx), ctx->xf,
-                     ctx->sp, ctx->maxDepth, n, dpx, dpy, dss, dL);
+  bool const useBvh = ctx->accel == DMT_ACCEL_BVH;
+  size_t const threads = size_t((n + 63) / 64) * 64;
+  if (useBvh) {
+    if (!ctx->haveBvh) return fail(ctx, DMT_ERR_STATE, "dmt_test_trace_samples: BVH not built");
+    int const rcO = ensureOverflow(ctx, threads);
+    if (rcO) return rcO;
+  }
+  hipLaunchKernelGGL(k_test_trace, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, sceneView(ctx), bvhView(ctx, threads),
+                     useBvh, ctx->xf, ctx->sp, ctx->maxDepth, n, dpx, dpy, dss, dL);
   int rc = finishTest(ctx);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpy(L3, dL, size_t(n) * 12, hipMemcpyDeviceToHost));
@@ -1217,8 +1386,15 @@ int dmt_test_closest_hit(dmt_ctx* ctx, int nrays, const float* o3, const float* 
   int32_t* di = S.up<int32_t>(nullptr, size_t(nrays));
   float* dt = S.up<float>(nullptr, size_t(nrays));
   SCRATCH_CHECK(ctx, dO && dD && di && dt);
-  hipLaunchKernelGGL(k_test_closest, dim3((nrays + 63) / 64), dim3(64), 0, ctx->stream, sceneView(ctx), nrays,
-                     dO, dD, di, dt);
+  bool const useBvh = ctx->accel == DMT_ACCEL_BVH;
+  size_t const threads = size_t((nrays + 63) / 64) * 64;
+  if (useBvh) {
+    if (!ctx->haveBvh) return fail(ctx, DMT_ERR_STATE, "dmt_test_closest_hit: BVH not built");
+    int const rcO = ensureOverflow(ctx, threads);
+    if (rcO) return rcO;
+  }
+  hipLaunchKernelGGL(k_test_closest, dim3((nrays + 63) / 64), dim3(64), 0, ctx->stream, sceneView(ctx),
+                     bvhView(ctx, threads), useBvh, nrays, dO, dD, di, dt);
   int rc = finishTest(ctx);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpy(tri_index, di, size_t(nrays) * 4, hipMemcpyDeviceToHost));

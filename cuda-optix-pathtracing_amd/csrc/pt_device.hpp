@@ -381,29 +381,6 @@ struct MTResult {
   bool valid;
   float t, u, v;
 };
-DMT_DEV MTResult mt_test(f3 p0, f3 e0, f3 e1, Ray const& ray) {
-  f3 const dxe1 = mk3(ray.d.y * e1.z - ray.d.z * e1.y, ray.d.z * e1.x - ray.d.x * e1.z,
-                      ray.d.x * e1.y - ray.d.y * e1.x);
-  float const det = dxe1.x * e0.x + dxe1.y * e0.y + dxe1.z * e0.z;
-  // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: this is the hot loop, and the
-  // reference's own GPU build divides with -use_fast_math (cmake/Config.cmake:465)
-  float const invDet = __builtin_amdgcn_rcpf(det);
-  f3 const ov = mk3(ray.o.x - p0.x, ray.o.y - p0.y, ray.o.z - p0.z);
-  f3 const txe0 = mk3(ov.y * e0.z - ov.z * e0.y, ov.z * e0.x - ov.x * e0.z,
-                      ov.x * e0.y - ov.y * e0.x);
-  float const u = invDet * (dxe1.x * ov.x + dxe1.y * ov.y + dxe1.z * ov.z);
-  float const v = invDet * (txe0.x * ray.d.x + txe0.y * ray.d.y + txe0.z * ray.d.z);
-  float const t = invDet * (txe0.x * e1.x + txe0.y * e1.y + txe0.z * e1.z);
-  float const tol = 1e-7f;
-  MTResult r;
-  r.valid = !(fabsf(det) < tol) && (u >= -tol && v >= -tol && (u + v) <= 1 + tol) && (t > 1e-4f);
-  r.t = t, r.u = u, r.v = v;
-  return r;
-}
-DMT_DEV MTResult mt_test(TriIsect const& T, Ray const& ray) {
-  return mt_test(mk3(T.p0x, T.p0y, T.p0z), mk3(T.e0x, T.e0y, T.e0z), mk3(T.e1x, T.e1y, T.e1z), ray);
-}
-
 // Two rays per lane in packed registers: component .x belongs to the lane's closest-hit ray,
 // .y to its pending shadow ray.  One v_pk_* instruction then advances both Moeller-Trumbore chains
 // (this is how CDNA reaches its fp32 peak), with the triangle in SGPRs broadcast to both halves.
@@ -417,27 +394,52 @@ struct TriS {  // one triangle held in scalars
 struct MTPair {
   v2f det, t, u, v;
 };
-DMT_DEV MTPair mt_pair(TriS const& T, RayPair const& r) {  // same operation order as mt_test
-  v2f const cx = r.dy * T.e1z - r.dz * T.e1y;
-  v2f const cy = r.dz * T.e1x - r.dx * T.e1z;
-  v2f const cz = r.dx * T.e1y - r.dy * T.e1x;
+// Moeller-Trumbore with every multiply-add spelled out, so that the packed two-ray form (brute-force
+// loop) and the scalar form (BVH leaves, test kernels) round identically: a triangle gives bit-equal
+// (det,t,u,v) whichever way it is reached.  Operation order = CC/private/shapes.cu:10-33 with
+// a*b+c -> fma(a,b,c) and the reciprocal by v_rcp_f32 (the reference's GPU build is -use_fast_math).
+DMT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+DMT_DEV v2f fma_(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+DMT_DEV v2f fma_(v2f a, float b, v2f c) { return __builtin_elementwise_fma(a, v2f{b, b}, c); }
+DMT_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+DMT_DEV v2f rcp_(v2f x) { return v2f{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+template <class T>
+DMT_DEV void mt_core(TriS const& t, T ox, T oy, T oz, T dx, T dy, T dz, T& det, T& tt, T& u, T& v) {
+  T const cx = fma_(dy, t.e1z, -(dz * t.e1y));
+  T const cy = fma_(dz, t.e1x, -(dx * t.e1z));
+  T const cz = fma_(dx, t.e1y, -(dy * t.e1x));
+  det = fma_(cz, t.e0z, fma_(cy, t.e0y, cx * t.e0x));
+  T const inv = rcp_(det);
+  T const ovx = ox - t.p0x, ovy = oy - t.p0y, ovz = oz - t.p0z;
+  T const qx = fma_(ovy, t.e0z, -(ovz * t.e0y));
+  T const qy = fma_(ovz, t.e0x, -(ovx * t.e0z));
+  T const qz = fma_(ovx, t.e0y, -(ovy * t.e0x));
+  u = inv * fma_(cz, ovz, fma_(cy, ovy, cx * ovx));
+  v = inv * fma_(qz, dz, fma_(qy, dy, qx * dx));
+  tt = inv * fma_(qz, t.e1z, fma_(qy, t.e1y, qx * t.e1x));
+}
+DMT_DEV MTPair mt_pair(TriS const& T, RayPair const& r) {
   MTPair m;
-  m.det = cx * T.e0x + cy * T.e0y + cz * T.e0z;
-  v2f inv;
-  inv.x = __builtin_amdgcn_rcpf(m.det.x);
-  inv.y = __builtin_amdgcn_rcpf(m.det.y);
-  v2f const ovx = r.ox - T.p0x, ovy = r.oy - T.p0y, ovz = r.oz - T.p0z;
-  v2f const qx = ovy * T.e0z - ovz * T.e0y;
-  v2f const qy = ovz * T.e0x - ovx * T.e0z;
-  v2f const qz = ovx * T.e0y - ovy * T.e0x;
-  m.u = inv * (cx * ovx + cy * ovy + cz * ovz);
-  m.v = inv * (qx * r.dx + qy * r.dy + qz * r.dz);
-  m.t = inv * (qx * T.e1x + qy * T.e1y + qz * T.e1z);
+  mt_core<v2f>(T, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, m.det, m.t, m.u, m.v);
   return m;
 }
 DMT_DEV bool mt_valid(float det, float t, float u, float v) {  // shapes.cu:19,35-38
   float const tol = 1e-7f;
   return !(fabsf(det) < tol) && (u >= -tol && v >= -tol && (u + v) <= 1 + tol) && (t > 1e-4f);
+}
+
+DMT_DEV MTResult mt_test(f3 p0, f3 e0, f3 e1, Ray const& ray) {
+  TriS T;
+  T.p0x = p0.x, T.p0y = p0.y, T.p0z = p0.z, T.e0x = e0.x, T.e0y = e0.y, T.e0z = e0.z;
+  T.e1x = e1.x, T.e1y = e1.y, T.e1z = e1.z;
+  float det;
+  MTResult r;
+  mt_core<float>(T, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, det, r.t, r.u, r.v);
+  r.valid = mt_valid(det, r.t, r.u, r.v);
+  return r;
+}
+DMT_DEV MTResult mt_test(TriIsect const& T, Ray const& ray) {
+  return mt_test(mk3(T.p0x, T.p0y, T.p0z), mk3(T.e0x, T.e0y, T.e0z), mk3(T.e1x, T.e1y, T.e1z), ray);
 }
 
 struct Hit {

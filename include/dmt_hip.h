@@ -117,6 +117,12 @@ int dmt_kernel_time(dmt_ctx* ctx, double* total_ms, uint64_t* launches, int rese
 int dmt_kernel_info(dmt_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* blocks_per_cu,
                     int* cu_count);
 
+/* host-only check of the BVH builder behind DMT_ACCEL_BVH (no GPU needed): builds the tree of a soup
+ * and verifies that every triangle sits in exactly one leaf, child boxes nest and enclose their
+ * vertices, leaves hold <= 4 triangles and the depth respects the traversal-stack bound */
+int dmt_bvh_validate(const float* xs, const float* ys, const float* zs, size_t count, int* node_count,
+                     int* depth, int* max_leaf);
+
 /* ---- device unit-test entry points (GPU twins of the reference's T/tests kernels) ---------- */
 int dmt_test_triangle_intersect(dmt_ctx* ctx, const float* xs, const float* ys, const float* zs,
                                 size_t count, const float* o3, const float* d3, int32_t* hit,

@@ -89,3 +89,38 @@ def test_random_triangle_scene_is_deterministic(H):
     c = np.stack([a.xs[:, :3].mean(1), a.ys[:, :3].mean(1), a.zs[:, :3].mean(1)], 1)
     assert c[:, 1].min() > 4.8 and c[:, 1].max() < 25.2 and abs(c[:, 0]).max() < 10.2
     assert H.random_triangle_scene(100, seed=1).xs[0, 0] != a.xs[0, 0]
+
+
+# ---- BVH builder (host part of DMT_ACCEL_BVH) ---------------------------------------------------
+def _soup(n, seed, spread=1.0, size=0.2):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-spread, spread, (n, 1, 3))
+    v = c + rng.uniform(-size, size, (n, 3, 3))
+    xs = np.zeros((n, 4), np.float32); ys = np.zeros((n, 4), np.float32); zs = np.zeros((n, 4), np.float32)
+    xs[:, :3], ys[:, :3], zs[:, :3] = v[..., 0], v[..., 1], v[..., 2]
+    return xs, ys, zs
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 26, 1000, 50000])
+def test_bvh_builder_invariants(pkg, n):
+    xs, ys, zs = _soup(n, n + 1)
+    r = pkg.bvh_validate(xs, ys, zs)
+    assert r["ok"], r
+    assert r["max_leaf"] <= 4 and r["depth"] <= 48
+    if n > 4:
+        assert r["node_count"] <= n          # never more nodes than triangles
+
+
+def test_bvh_builder_degenerate_inputs(pkg, H):
+    # all triangles identical (zero centroid extent): median fallback must still terminate
+    xs, ys, zs = _soup(1, 3)
+    xs, ys, zs = np.repeat(xs, 300, 0), np.repeat(ys, 300, 0), np.repeat(zs, 300, 0)
+    assert pkg.bvh_validate(xs, ys, zs)["ok"]
+    # collinear centroids, zero-area triangles
+    xs, ys, zs = _soup(200, 4)
+    ys[:] = 0; zs[:] = 0
+    assert pkg.bvh_validate(xs, ys, zs)["ok"]
+    # the reference's scene
+    s = H.cornell_box()
+    r = pkg.bvh_validate(s.xs, s.ys, s.zs)
+    assert r["ok"] and r["depth"] <= 4

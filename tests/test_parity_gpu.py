@@ -397,3 +397,91 @@ def test_full_size_invariants(renderer, O):
     assert np.isfinite(mean).all() and np.all(m2[..., 3] == 16) and (m2[..., :3] >= 0).all()
     rmean, _ = O.render(scene, 16, max_depth=8, region=(0, 500, 1024, 516))
     assert film_rmse(mean[500:516], rmean[500:516]) < 1e-4
+
+
+# ---- BVH (DMT_ACCEL_BVH): must reproduce brute force exactly ---------------------------------------
+def _random_soup(n, seed, spread=3.0, size=0.35):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-spread, spread, (n, 1, 3)) + np.array([0, 6.0, 0])
+    v = c + rng.uniform(-size, size, (n, 3, 3))
+    xs = np.zeros((n, 4), np.float32); ys = np.zeros((n, 4), np.float32); zs = np.zeros((n, 4), np.float32)
+    xs[:, :3], ys[:, :3], zs[:, :3] = v[..., 0], v[..., 1], v[..., 2]
+    return xs, ys, zs
+
+
+def _rays(n, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 1] = np.abs(d[:, 1]) + 0.3
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d.astype(np.float32)
+
+
+@pytest.mark.parametrize("ntri", [1, 5, 26, 777, 20000])
+def test_bvh_closest_hit_equals_brute_force(renderer, O, ntri):
+    xs, ys, zs = _random_soup(ntri, ntri)
+    if ntri == 777:          # duplicates: ties must resolve to the lowest ORIGINAL index
+        xs[400:] = xs[:377]; ys[400:] = ys[:377]; zs[400:] = zs[:377]
+    renderer.upload_triangles(xs, ys, zs, np.zeros(ntri, np.uint32))
+    o, d = _rays(8192, ntri + 1)
+    renderer.set_accel(0)
+    bi, bt = renderer.test_closest_hit(o, d)
+    renderer.set_accel(1)
+    ai, at = renderer.test_closest_hit(o, d)
+    renderer.set_accel(0)
+    assert np.array_equal(ai, bi)
+    assert np.array_equal(at.view(np.uint32), bt.view(np.uint32))      # same routine on the same record: bit equal
+    oi, ot = O.closest_hit(xs, ys, zs, o[:2048], d[:2048])
+    assert (ai[:2048] != oi).sum() <= 1                               # vs the CPU oracle: float-rounding edge cases only
+    if ntri >= 777:
+        assert (ai >= 0).mean() > 0.02
+    if ntri == 777:
+        assert ai.max() < 400 or (ai[ai >= 377] < 400).all()          # never the duplicate copy
+
+
+def test_bvh_film_bit_exact_vs_brute_force(renderer, pkg, O):
+    """Whole path tracer through the BVH == brute force, bit for bit (closest hits, shadow rays, ties)."""
+    for scene, res, spp in ((pkg.host_scene.cornell_box(64, 64), 64, 16),
+                            (pkg.host_scene.random_triangle_scene(4000, width=48, height=48), 48, 4)):
+        renderer.upload_scene(scene)
+        renderer.set_limits(8)
+        films = []
+        for mode in (0, 1):
+            renderer.set_accel(mode)
+            renderer.film_clear()
+            renderer.render(spp)
+            films.append(renderer.download_film())
+        renderer.set_accel(0)
+        assert np.array_equal(films[0][0], films[1][0]) and np.array_equal(films[0][1], films[1][1])
+        assert films[0][0][..., :3].max() > 0
+
+
+def test_bvh_million_triangles(renderer, pkg, O):
+    """BASELINE config 4 scene (1 M random triangles): BVH == brute force on a few tiles (brute force
+    costs 1 M tests per ray, so only 4 tiles x 1 spp), and vs the CPU oracle on 32 camera rays."""
+    scene = pkg.host_scene.random_triangle_scene(1_000_000, width=1024, height=1024)
+    assert pkg.bvh_validate(scene.xs, scene.ys, scene.zs)["ok"]
+    renderer.upload_scene(scene)
+    renderer.set_limits(3)
+    region = (496, 504, 528, 512)               # 4 tiles in the middle of the frame
+    films = []
+    for mode in (0, 1):
+        renderer.set_accel(mode)
+        renderer.film_clear()
+        renderer.render(1, region=region)
+        films.append(renderer.download_film())
+    assert np.array_equal(films[0][0], films[1][0]) and np.array_equal(films[0][1], films[1][1])
+    assert np.all(films[1][1][504:512, 496:528, 3] == 1)
+    o, d = _rays(32, 99)
+    o[:] = 0
+    ai, at = renderer.test_closest_hit(o, d)            # accel still BVH
+    oi, ot = O.closest_hit(scene.xs, scene.ys, scene.zs, o, d)
+    assert np.array_equal(ai, oi)
+    # a larger BVH-only render stays finite and fully sampled
+    renderer.set_limits(8)
+    renderer.film_clear()
+    renderer.render(4, region=(256, 256, 768, 768))
+    mean, m2 = renderer.download_film()
+    assert np.isfinite(mean).all() and np.all(m2[256:768, 256:768, 3] == 4)
+    renderer.set_accel(0)
