@@ -36,7 +36,10 @@ WORKLOADS = {
     "cornell_1024x1024_1024spp_8bounces": (1024, 1024, 1024, 8, "cornell"),
     "cornell_256x256_2048spp_32bounces": (256, 256, 2048, 32, "cornell"),   # the reference's own published run
     "cornell_512x512_64spp_4bounces": (512, 512, 64, 4, "cornell"),         # BASELINE configs[0]
+    # BASELINE configs[3]: 1 M random triangles (SURVEY 8d generator), the memory-bound point; BVH traversal
+    "random1M_1024x1024_512spp_8bounces": (1024, 1024, 512, 8, "random1M"),
 }
+BVH_NODE_BYTES = 128
 DEFAULT_WORKLOAD = "cornell_1024x1024_1024spp_8bounces"
 
 # Per-sample work counters of each workload, counted by the CPU restatement on rows spread evenly over
@@ -97,9 +100,13 @@ def main():
     import __graft_entry__ as graft
     pkg = graft.load_package()
 
-    width, height, spp, max_depth, _ = WORKLOADS[args.workload]
+    width, height, spp, max_depth, scene_kind = WORKLOADS[args.workload]
     kspp = args.kspp if args.kspp > 0 else spp
-    scene = pkg.host_scene.cornell_box(width, height)
+    use_bvh = scene_kind != "cornell"
+    if scene_kind == "cornell":
+        scene = pkg.host_scene.cornell_box(width, height)
+    else:
+        scene = pkg.host_scene.random_triangle_scene(1_000_000, width=width, height=height)
 
     r = pkg.Renderer(dev_index)
     # one explicit (non-null) stream for everything: film zeroing, kernels + their HIP timing events,
@@ -110,6 +117,8 @@ def main():
     r.set_stream(stream.cuda_stream)
     r.upload_scene(scene)
     r.set_limits(max_depth)
+    if use_bvh:
+        r.set_accel(1)
     r.set_partition(rank, world)
     mean = torch.zeros((height, width, 4), dtype=torch.float32, device=dev)
     m2 = torch.zeros((height, width, 4), dtype=torch.float32, device=dev)
@@ -156,7 +165,35 @@ def main():
         roofline = None
         parity = None
         stats = None
-        if not args.no_cpu_baseline and world == 1:
+        bvh_stats = None
+        if use_bvh:
+            # BVH path: node visits / triangle tests come from the counting build of the same kernel
+            # (1 spp over the whole frame; the film is rebuilt by nothing afterwards -- timing is done)
+            r.set_partition(0, 1)
+            bvh_stats = r.render_stats(1, sample_offset=spp)
+            stats = {"samples": bvh_stats["samples"], "tri_tests": bvh_stats["tri_tests"],
+                     "bounces": bvh_stats["bounces"], "hits": bvh_stats["bounces"],
+                     "node_visits": bvh_stats["node_visits"], "closest_rays": bvh_stats["closest_rays"],
+                     "shadow_rays": bvh_stats["shadow_rays"]}
+            if not args.no_cpu_baseline and world == 1:
+                # the reference arithmetic is brute force: 1 M triangle tests per ray.  32 samples only.
+                O = graft.load_oracle()
+                oscene = O.Scene(scene.xs, scene.ys, scene.zs, scene.mat_id, scene.bsdfs, scene.lights,
+                                 scene.inf_lights, scene.camera)
+                threads = int(os.environ.get("DMT_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+                y = height // 2
+                tc = time.perf_counter()
+                omean, om2, ost = O.render(oscene, 1, max_depth=max_depth, region=(width // 2 - 16, y, width // 2 + 16, y + 1),
+                                           threads=threads, want_stats=True)
+                tcpu = time.perf_counter() - tc
+                cpu_baseline = {
+                    "value": round(ost["samples"] / tcpu / 1e6, 8), "unit": "Msamples/s", "cores": threads, "kind": "port",
+                    "sample": f"32 pixels x 1 spp of row {y} ({tcpu:.1f} s); the reference arithmetic is a brute-force loop "
+                              f"over all 1,000,000 triangles per ray (megakernel.cu:121-133), no BVH",
+                }
+                d = film_mean[y, width // 2 - 16:width // 2 + 16, :3].astype(np.float64)
+                # spp differs (1 vs 0) so this is not a parity figure; parity of the BVH path is tests/test_parity_gpu.py::test_bvh_*
+        elif not args.no_cpu_baseline and world == 1:
             O = graft.load_oracle()          # cpu_baseline leg: the oracle is the thing timed
             oscene = O.cornell_box(width, height)
             nrows = max(1, min(args.cpu_band_rows, height))
@@ -189,6 +226,8 @@ def main():
             my_items = (width // 8) * (height // 8)
             samples_per_launch = float(width) * height * kspp / world
             b_sample = algorithmic_bytes_per_sample(stats, kspp)
+            if use_bvh:
+                b_sample += stats["node_visits"] * float(BVH_NODE_BYTES) / stats["samples"]
             achieved = b_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9
             traffic = None
             pmc = ROOT / "profiles" / "pmc_summary.json"
@@ -203,16 +242,20 @@ def main():
             roofline = {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "k_megakernel", "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
+                "kernel": "k_megakernel_bvh" if use_bvh else "k_megakernel", "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
                 "algorithmic_bytes_per_sample": round(b_sample, 1),
-                "note": "26-triangle scene is cache/SGPR resident: algorithmic bytes are served by the scalar cache, "
-                        "the kernel is VALU/latency bound (SURVEY 8d); see valu_view",
+                "note": ("1 M triangles (48 MB) + BVH nodes exceed L2; per-lane incoherent node/triangle gathers: "
+                         "memory-latency bound" if use_bvh else
+                         "26-triangle scene is cache/SGPR resident: algorithmic bytes are served by the scalar cache, "
+                         "the kernel is VALU/latency bound (SURVEY 8d); see valu_view"),
+                "per_sample": {k: round(v / stats["samples"], 3) for k, v in stats.items() if k != "samples"},
                 "valu_view": {
                     "achieved_tflops": round(flops_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e12, 3),
                     "peak_tflops": FP32_VALU_PEAK_TFLOPS,
                     "flops_model": "60 flop x triangle tests (intersection only; shading and sampler not counted)",
                 },
-                "vgprs": info["vgprs"], "blocks_per_cu": info["blocks_per_cu"], "cu_count": info["cu_count"],
+                "vgprs": info["vgprs"], "lds_bytes_per_block": info["lds_bytes"], "blocks_per_cu": info["blocks_per_cu"],
+                "cu_count": info["cu_count"],
             }
 
         out = {
@@ -220,9 +263,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "scene": "cornellBox() (26 triangles, spot + constant env)",
+            "config": {"workload": args.workload,
+                       "scene": "cornellBox() (26 triangles, spot + constant env)" if not use_bvh else
+                                "1,000,000 random triangles, splitmix64 seed 0x5EED1234 (SURVEY 8d), Cornell BSDFs, spot + env",
                        "width": width, "height": height, "spp": spp, "max_depth": max_depth, "kspp": kspp,
-                       "accel": "brute_force", "partition": f"interleaved 8x8 tiles over {world} GPU(s)",
+                       "accel": "bvh4" if use_bvh else "brute_force", "partition": f"interleaved 8x8 tiles over {world} GPU(s)",
                        "combine": "rccl reduce(sum) of mean/M2 frames to rank 0" if world > 1 else "none"},
             "film_ok": counts_ok,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,

@@ -53,7 +53,7 @@ EXPORTED_SYMBOLS = [
     "dmt_ctx_create", "dmt_ctx_destroy", "dmt_last_error", "dmt_upload_triangles", "dmt_upload_bsdfs",
     "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_partition",
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
-    "dmt_render", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
+    "dmt_render", "dmt_render_stats", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
     "dmt_test_sampler", "dmt_test_camera_rays", "dmt_test_bsdf", "dmt_test_light", "dmt_test_half",
     "dmt_test_trace_samples", "dmt_test_trace_log", "dmt_test_closest_hit",
 ]
@@ -185,6 +185,14 @@ class Renderer:
         x0, y0, x1, y1 = region if region is not None else (0, 0, self.width, self.height)
         self._check(self._lib.dmt_render(self._ctx, C.c_uint32(sample_offset), C.c_uint32(spp), int(x0), int(y0),
                                          int(x1), int(y1)), "dmt_render")
+
+    def render_stats(self, spp, sample_offset=0, region=None):
+        x0, y0, x1, y1 = region if region is not None else (0, 0, self.width, self.height)
+        out = np.zeros(6, np.uint64)
+        self._check(self._lib.dmt_render_stats(self._ctx, C.c_uint32(sample_offset), C.c_uint32(spp), int(x0), int(y0),
+                                               int(x1), int(y1), _p(out)), "dmt_render_stats")
+        keys = ["samples", "closest_rays", "shadow_rays", "node_visits", "tri_tests", "bounces"]
+        return dict(zip(keys, (int(v) for v in out)))
 
     def sync(self):
         self._check(self._lib.dmt_sync(self._ctx), "dmt_sync")

@@ -79,9 +79,14 @@ DMT_DEV TriS tri_from(TriIsect const& T) {
   return t;
 }
 
+struct TraversalCounters {  // per-lane work counters (stats build of the kernel only)
+  uint32_t nodes = 0, tris = 0;
+};
+
 // closest hit: bestTri = ORIGINAL triangle index or -1
+template <bool STATS = false>
 DMT_DEV void bvh_closest(BvhView const& bv, bool active, f3 o, f3 d, uint32_t gtid, int& bestTri, float& bt,
-                         float& bu, float& bvv) {
+                         float& bu, float& bvv, TraversalCounters* tc = nullptr) {
   bt = kInf, bestTri = -1, bu = 0.f, bvv = 0.f;
   uint32_t bestOrig = 0xFFFFFFFFu;
   SlabRay const sr = slab_ray(o, d);
@@ -90,6 +95,7 @@ DMT_DEV void bvh_closest(BvhView const& bv, bool active, f3 o, f3 d, uint32_t gt
   while (cur != kBvhEmpty) {
     if (!(cur & kBvhLeafFlag)) {
       Bvh4Node const& n = bv.nodes[cur];
+      if constexpr (STATS) ++tc->nodes;
       float k0 = slab(sr, n.minx[0], n.miny[0], n.minz[0], n.maxx[0], n.maxy[0], n.maxz[0], bt);
       float k1 = slab(sr, n.minx[1], n.miny[1], n.minz[1], n.maxx[1], n.maxy[1], n.maxz[1], bt);
       float k2 = slab(sr, n.minx[2], n.miny[2], n.minz[2], n.maxx[2], n.maxy[2], n.maxz[2], bt);
@@ -110,6 +116,7 @@ DMT_DEV void bvh_closest(BvhView const& bv, bool active, f3 o, f3 d, uint32_t gt
     } else {
       uint32_t const first = cur & 0x0FFFFFFFu;
       uint32_t const cnt = ((cur >> 28) & 7u) + 1u;
+      if constexpr (STATS) tc->tris += cnt;
       for (uint32_t j = 0; j < cnt; ++j) {
         TriIsect const T = bv.tris[first + j];
         float det, t, u, v;
@@ -125,7 +132,9 @@ DMT_DEV void bvh_closest(BvhView const& bv, bool active, f3 o, f3 d, uint32_t gt
 }
 
 // any hit with t < tmax
-DMT_DEV bool bvh_any(BvhView const& bv, bool active, f3 o, f3 d, float tmax, uint32_t gtid) {
+template <bool STATS = false>
+DMT_DEV bool bvh_any(BvhView const& bv, bool active, f3 o, f3 d, float tmax, uint32_t gtid,
+                     TraversalCounters* tc = nullptr) {
   SlabRay const sr = slab_ray(o, d);
   BvhStack st{0, bv.overflow + gtid, bv.overflowStride};
   uint32_t cur = active ? 0u : kBvhEmpty;
@@ -133,6 +142,7 @@ DMT_DEV bool bvh_any(BvhView const& bv, bool active, f3 o, f3 d, float tmax, uin
   while (cur != kBvhEmpty) {
     if (!(cur & kBvhLeafFlag)) {
       Bvh4Node const& n = bv.nodes[cur];
+      if constexpr (STATS) ++tc->nodes;
       float const k0 = slab(sr, n.minx[0], n.miny[0], n.minz[0], n.maxx[0], n.maxy[0], n.maxz[0], tmax);
       float const k1 = slab(sr, n.minx[1], n.miny[1], n.minz[1], n.maxx[1], n.maxy[1], n.maxz[1], tmax);
       float const k2 = slab(sr, n.minx[2], n.miny[2], n.minz[2], n.maxx[2], n.maxy[2], n.maxz[2], tmax);
@@ -156,6 +166,7 @@ DMT_DEV bool bvh_any(BvhView const& bv, bool active, f3 o, f3 d, float tmax, uin
     } else {
       uint32_t const first = cur & 0x0FFFFFFFu;
       uint32_t const cnt = ((cur >> 28) & 7u) + 1u;
+      if constexpr (STATS) tc->tris += cnt;
       for (uint32_t j = 0; j < cnt; ++j) {
         TriIsect const T = bv.tris[first + j];
         float det, t, u, v;

@@ -48,6 +48,7 @@ struct RenderParams {
   int rank, world;
   uint32_t sampleOffset, spp;
   int maxDepth;
+  unsigned long long* stats;  // stats build only: samples, closest rays, shadow rays, node visits, triangle tests, bounces
 };
 
 // Per-lane state.  A lane carries (a) the path it is currently extending and (b) at most one
@@ -215,29 +216,36 @@ DMT_DEV void trace_pair_brute(SceneView const& sc, PathState const& st, bool doC
 
 // BVH flavour of the pass: closest-hit traversal for the path ray, then any-hit traversal for the
 // pending shadow ray.  Results are identical to trace_pair_brute (same triangle test, same tie rule).
+struct LaneStats {  // stats build only
+  uint32_t samples = 0, closest = 0, shadow = 0, bounces = 0;
+  TraversalCounters tc;
+};
+template <bool STATS = false>
 DMT_DEV void trace_pair_bvh(BvhView const& bvh, PathState const& st, bool doC, bool doS, uint32_t gtid,
-                            int& bestTri, float& bu, float& bv, bool& occluded) {
+                            int& bestTri, float& bu, float& bv, bool& occluded, LaneStats* ls = nullptr) {
   float bt;
-  bvh_closest(bvh, doC, mk3(st.rp.ox.x, st.rp.oy.x, st.rp.oz.x), mk3(st.rp.dx.x, st.rp.dy.x, st.rp.dz.x), gtid,
-              bestTri, bt, bu, bv);
-  occluded = bvh_any(bvh, doS, mk3(st.rp.ox.y, st.rp.oy.y, st.rp.oz.y), mk3(st.rp.dx.y, st.rp.dy.y, st.rp.dz.y),
-                     st.smax, gtid);
+  if constexpr (STATS) ls->closest += doC ? 1u : 0u, ls->shadow += doS ? 1u : 0u;
+  bvh_closest<STATS>(bvh, doC, mk3(st.rp.ox.x, st.rp.oy.x, st.rp.oz.x), mk3(st.rp.dx.x, st.rp.dy.x, st.rp.dz.x),
+                     gtid, bestTri, bt, bu, bv, STATS ? &ls->tc : nullptr);
+  occluded = bvh_any<STATS>(bvh, doS, mk3(st.rp.ox.y, st.rp.oy.y, st.rp.oz.y),
+                            mk3(st.rp.dx.y, st.rp.dy.y, st.rp.dz.y), st.smax, gtid, STATS ? &ls->tc : nullptr);
 }
 
 // One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
 // sink(L) is called once per completed sample, in sample order.
-template <bool BVH, class Sink>
+template <bool BVH, bool STATS = false, class Sink>
 DMT_DEV void lane_step(SceneView const& sc, BvhView const& bvh, uint32_t gtid, int maxDepth, PathState& st,
-                       Sink&& sink) {
+                       Sink&& sink, LaneStats* ls = nullptr) {
   bool const doC = st.active;
   bool const doS = st.hasShadow;
   int bestTri;
   float bu, bv;
   bool occluded;
   if constexpr (BVH)
-    trace_pair_bvh(bvh, st, doC, doS, gtid, bestTri, bu, bv, occluded);
+    trace_pair_bvh<STATS>(bvh, st, doC, doS, gtid, bestTri, bu, bv, occluded, ls);
   else
     trace_pair_brute(sc, st, doC, doS, bestTri, bu, bv, occluded);
+  if constexpr (STATS) ls->bounces += (doC && bestTri >= 0 && st.depth < maxDepth) ? 1u : 0u;
   if (doS) {
     st.hasShadow = false;
     if (st.finPending) {  // the shadow ray of an already finished sample
@@ -306,8 +314,9 @@ DMT_DEV void path_begin_prepared(PathState& st) {
 #ifndef DMT_PREP_THRESHOLD
 #define DMT_PREP_THRESHOLD 64
 #endif
-template <bool BVH>
+template <bool BVH, bool STATS = false>
 DMT_DEV void megakernel_body(RenderParams const& P) {
+  LaneStats ls;
   int const lane = int(threadIdx.x) & 63;
   uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
   float* const film = s_film + threadIdx.x;
@@ -361,9 +370,10 @@ DMT_DEV void megakernel_body(RenderParams const& P) {
       if (!st.active && sNext < sPrep) {
         path_begin_prepared(st);
         ++sNext;
+        if constexpr (STATS) ++ls.samples;
       }
       if (!__any(st.active || st.hasShadow)) break;
-      lane_step<BVH>(P.scene, P.bvh, gtid, P.maxDepth, st, welford);
+      lane_step<BVH, STATS>(P.scene, P.bvh, gtid, P.maxDepth, st, welford, STATS ? &ls : nullptr);
     }
     if (inside) {  // endSample, megakernel.cuh:81-85
       P.mean[pidx] = make_float4(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads], 0.f);
@@ -371,12 +381,23 @@ DMT_DEV void megakernel_body(RenderParams const& P) {
                                film[6 * kLdsThreads]);
     }
   }
+  if constexpr (STATS) {
+    atomicAdd(&P.stats[0], (unsigned long long)ls.samples);
+    atomicAdd(&P.stats[1], (unsigned long long)ls.closest);
+    atomicAdd(&P.stats[2], (unsigned long long)ls.shadow);
+    atomicAdd(&P.stats[3], (unsigned long long)ls.tc.nodes);
+    atomicAdd(&P.stats[4], (unsigned long long)ls.tc.tris);
+    atomicAdd(&P.stats[5], (unsigned long long)ls.bounces);
+  }
 }
 
 // brute force: the reference's semantics, every triangle tested (small scenes, parity mode)
 __global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD) k_megakernel(RenderParams P) { megakernel_body<false>(P); }
 // BVH traversal (large scenes); 16 KB more LDS per block for the traversal stacks
 __global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD_BVH) k_megakernel_bvh(RenderParams P) { megakernel_body<true>(P); }
+// same kernel with per-lane work counters (node visits, triangle tests, rays, bounces): feeds the
+// algorithmic-bytes model of the BVH path; never on the timed path
+__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats(RenderParams P) { megakernel_body<true, true>(P); }
 
 // ---------------------------------------------------------------------------------------------
 // device unit-test kernels
@@ -1026,8 +1047,9 @@ int dmt_download_film(dmt_ctx* ctx, float* mean4, float* m24) {
   return DMT_OK;
 }
 
-int dmt_render(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1) {
+static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1, uint64_t* stats6) {
   if (!ctx) return DMT_ERR_INVALID;
+  if (stats6) memset(stats6, 0, 6 * sizeof(uint64_t));
   if (!(ctx->haveTris && ctx->haveBsdfs && ctx->haveLights && ctx->haveCamera))
     return fail(ctx, DMT_ERR_STATE, "dmt_render: upload triangles, bsdfs, lights and set the camera first");
   // the Halton index sample * stride must stay inside int32 (CC/private/rng.cu:229)
@@ -1082,6 +1104,19 @@ int dmt_render(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y
     int const rcO = ensureOverflow(ctx, size_t(ctx->cuCount) * size_t(ctx->blocksPerCUBvh) * 256);
     if (rcO) return rcO;
     P.bvh = bvhView(ctx, size_t(blocks) * 256);
+    if (stats6) {
+      unsigned long long* dstats = nullptr;
+      HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dstats), 6 * sizeof(unsigned long long)));
+      HIP_TRY(ctx, hipMemsetAsync(dstats, 0, 6 * sizeof(unsigned long long), ctx->stream));
+      P.stats = dstats;
+      hipLaunchKernelGGL(k_megakernel_bvh_stats, dim3(blocks), dim3(256), 0, ctx->stream, P);
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess) e = hipMemcpy(stats6, dstats, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      (void)hipFree(dstats);
+      HIP_TRY(ctx, e);
+      return DMT_OK;
+    }
     hipLaunchKernelGGL(k_megakernel_bvh, dim3(blocks), dim3(256), 0, ctx->stream, P);
   } else {
     hipLaunchKernelGGL(k_megakernel, dim3(blocks), dim3(256), 0, ctx->stream, P);
@@ -1142,6 +1177,19 @@ int dmt_bvh_validate(const float* xs, const float* ys, const float* zs, size_t c
   return ok && maxLeaf <= kBvhMaxLeafTris ? DMT_OK : DMT_ERR_STATE;
 }
 
+static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1, uint64_t* stats6);
+
+int dmt_render(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1) {
+  return renderImpl(ctx, sample_offset, spp, x0, y0, x1, y1, nullptr);
+}
+
+int dmt_render_stats(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1,
+                     uint64_t* stats6) {
+  if (!ctx || !stats6) return DMT_ERR_INVALID;
+  if (ctx->accel != DMT_ACCEL_BVH) return fail(ctx, DMT_ERR_STATE, "dmt_render_stats: only the BVH path has device counters");
+  return renderImpl(ctx, sample_offset, spp, x0, y0, x1, y1, stats6);
+}
+
 int dmt_sync(dmt_ctx* ctx) {
   if (!ctx) return DMT_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1169,11 +1217,13 @@ int dmt_kernel_time(dmt_ctx* ctx, double* total_ms, uint64_t* launches, int rese
 int dmt_kernel_info(dmt_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* blocks_per_cu, int* cu_count) {
   if (!ctx) return DMT_ERR_INVALID;
   hipFuncAttributes attr{};
-  HIP_TRY(ctx, hipFuncGetAttributes(&attr, reinterpret_cast<void const*>(k_megakernel)));
+  bool const useBvh = ctx->accel == DMT_ACCEL_BVH;  // facts of the kernel dmt_render would launch now
+  HIP_TRY(ctx, hipFuncGetAttributes(&attr, useBvh ? reinterpret_cast<void const*>(k_megakernel_bvh)
+                                                  : reinterpret_cast<void const*>(k_megakernel)));
   if (vgprs) *vgprs = attr.numRegs;
   if (sgprs) *sgprs = 0;
   if (lds_bytes) *lds_bytes = int(attr.sharedSizeBytes);
-  if (blocks_per_cu) *blocks_per_cu = ctx->blocksPerCU;
+  if (blocks_per_cu) *blocks_per_cu = useBvh ? ctx->blocksPerCUBvh : ctx->blocksPerCU;
   if (cu_count) *cu_count = ctx->cuCount;
   return DMT_OK;
 }

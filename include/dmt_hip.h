@@ -108,6 +108,11 @@ int dmt_download_film(dmt_ctx* ctx, float* mean4, float* m24);
  * [x0,x1) x [y0,y1) are traced and folded into the film (Welford, in sample order).
  * Asynchronous on the context's stream. */
 int dmt_render(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1);
+/* Same pass through the counting build of the BVH kernel (synchronous, not for timing): stats6 =
+ * {samples, closest-hit rays, shadow rays, BVH node visits, triangle tests, bounces}.  The film is
+ * updated exactly as by dmt_render. */
+int dmt_render_stats(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1,
+                     uint64_t* stats6);
 int dmt_sync(dmt_ctx* ctx);
 /* HIP-event time of the megakernel launches since the last reset (synchronises the stream):
  * total milliseconds and launch count. */
