@@ -56,6 +56,34 @@ struct RenderParams {
 // with its last shadow ray still untraced the lane parks that sample's radiance in Lfin and starts
 // the NEXT sample at once: the old shadow ray and the new camera ray share the next triangle pass,
 // and the parked sample is finalised (in order) right after it.
+// All kernels that trace paths take a RenderParams as their FIRST by-value argument, i.e. at offset 0 of
+// the kernarg segment.  Device code never touches that parameter object directly: it reads the fields it
+// needs, where it needs them, through the kernarg pointer behind an opaque barrier (`kargs`).  Left to
+// itself the compiler hoists all ~90 argument dwords to the top of the kernel and keeps them in SGPRs
+// across the triangle loop; that overflows the 102-SGPR file and the spill code lands INSIDE the hot
+// loop (measured: 97 ms -> 160 ms per launch).  An s_load from the scalar cache at the point of use
+// costs nothing next to the ~2-3k instructions of a shading step.
+typedef RenderParams const DMT_CONST_AS* KArgs;
+DMT_DEV KArgs kargs_base() { return (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); }
+DMT_DEV KArgs kargs(KArgs p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+DMT_DEV SceneView load_scene(KArgs k) {
+  k = kargs(k);
+  SceneView s;
+  s.tris = k->scene.tris, s.post = k->scene.post, s.bsdfs = k->scene.bsdfs, s.lights = k->scene.lights;
+  s.infLights = k->scene.infLights, s.triCount = k->scene.triCount, s.bsdfCount = k->scene.bsdfCount;
+  s.lightCount = k->scene.lightCount, s.infLightCount = k->scene.infLightCount;
+  return s;
+}
+DMT_DEV BvhView load_bvh(KArgs k) {
+  k = kargs(k);
+  BvhView b;
+  b.nodes = k->bvh.nodes, b.tris = k->bvh.tris, b.overflow = k->bvh.overflow, b.overflowStride = k->bvh.overflowStride;
+  return b;
+}
+
 struct PathState {
   RayPair rp;       // .x = current path's ray, .y = pending shadow ray
   f3 beta, L;
@@ -112,8 +140,9 @@ DMT_DEV void path_begin(PathState& st, CameraXf const& cam, SamplerParams const&
 // Everything between two ray casts (T/megakernel/megakernel.cu:135-295).  Returns true when the
 // path ends.  May leave a pending shadow ray (st.hasShadow) whose contribution st.C is added once
 // visibility is known.
-DMT_DEV bool path_shade(SceneView const& sc, int maxDepth, PathState& st, int bestTri, float bu,
-                        float bv) {
+DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv) {
+  SceneView const sc = load_scene(k);
+  int const maxDepth = kargs(k)->maxDepth;
   if (bestTri < 0) {  // miss: constant environment, no MIS (megakernel.cu:135-151)
     if (sc.infLightCount > 0) {
       uint32_t const li = pick_index(st.rng.get1D(), sc.infLightCount);
@@ -185,44 +214,68 @@ DMT_DEV TriS load_tri(TriIsect const DMT_CONST_AS* tris, uint32_t i) {
 
 // One pass over the triangle array for the lane's ray pair: closest hit for .x, any-hit for .y.
 // Brute force = the reference's semantics.  The loop index is wave-uniform and the array is read
-// through the constant address space, so each triangle arrives by s_load into SGPRs (prefetched one
-// iteration ahead) and the VALU work is packed fp32 over the two rays: no VGPR, LDS or
-// vector-memory traffic in the loop.
-DMT_DEV void trace_pair_brute(SceneView const& sc, PathState const& st, bool doC, bool doS,
-                              int& bestTri, float& bu, float& bv, bool& occluded) {
-  float bt = kInf;
-  bestTri = -1;
-  bu = 0.f, bv = 0.f;
-  occluded = false;
-  auto const* tris = to_const_as(sc.tris);
-  uint32_t const n = sc.triCount;
-  TriS cur = load_tri(tris, 0);  // the array always holds >= 1 record (devAlloc)
-  for (uint32_t i = 0; i < n; ++i) {
-    TriS const nxt = load_tri(tris, i + 1 < n ? i + 1 : i);
+// through the constant address space, so each triangle arrives by s_load into SGPRs, prefetched one
+// triangle ahead in a two-register ping-pong (no SGPR copies), and the VALU work is packed fp32 over the
+// two rays: no VGPR, LDS or vector-memory traffic in the loop.
+struct BruteHit {
+  float bt, bu, bv;
+  int tri;
+  bool occluded;
+};
+// nine named scalars per triangle (never a struct, see mt_core9)
+#define DMT_TRI_DECL(P) float P##0, P##1, P##2, P##3, P##4, P##5, P##6, P##7, P##8
+#define DMT_TRI_LOAD(P, idx)                                                                          \
+  P##0 = tris[idx].p0x, P##1 = tris[idx].p0y, P##2 = tris[idx].p0z, P##3 = tris[idx].e0x, P##4 = tris[idx].e0y, \
+  P##5 = tris[idx].e0z, P##6 = tris[idx].e1x, P##7 = tris[idx].e1y, P##8 = tris[idx].e1z
+#define DMT_TRI_TEST(P, idx)                                                                                   \
+  do {                                                                                                         \
+    MTPair m;                                                                                                  \
+    mt_core9<v2f>(P##0, P##1, P##2, P##3, P##4, P##5, P##6, P##7, P##8, st.rp.ox, st.rp.oy, st.rp.oz, st.rp.dx, \
+                  st.rp.dy, st.rp.dz, m.det, m.t, m.u, m.v);                                                   \
+    bool const v1 = mt_valid(m.det.x, m.t.x, m.u.x, m.v.x);                                                    \
+    bool const v2 = mt_valid(m.det.y, m.t.y, m.u.y, m.v.y);                                                    \
+    if (doC && v1 && m.t.x < h.bt) { /* strict <: lowest index wins ties (megakernel.cu:126) */                 \
+      h.bt = m.t.x;                                                                                            \
+      h.tri = int(idx);                                                                                        \
+      h.bu = m.u.x;                                                                                            \
+      h.bv = m.v.x;                                                                                            \
+    }                                                                                                          \
+    if (doS && v2 && m.t.y < st.smax) h.occluded = true; /* :210-211 */                                        \
+  } while (0)
+
+DMT_DEV void trace_pair_brute(KArgs k, PathState const& st, bool doC, bool doS, int& bestTri, float& bu,
+                              float& bv, bool& occluded) {
+  BruteHit h{kInf, 0.f, 0.f, -1, false};
+  k = kargs(k);
+  auto const* tris = to_const_as(k->scene.tris);
+  uint32_t const n = k->scene.triCount;
+  uint32_t const last = n ? n - 1 : 0;
+  DMT_TRI_DECL(a);
+  DMT_TRI_DECL(b);
+  DMT_TRI_LOAD(a, 0);  // the array always holds >= 1 record (devAlloc)
+  for (uint32_t i = 0; i < n;) {
+    uint32_t const ib = i + 1 < last ? i + 1 : last;
+    DMT_TRI_LOAD(b, ib);
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch s_loads above the arithmetic
-    MTPair const m = mt_pair(cur, st.rp);
-    bool const v1 = mt_valid(m.det.x, m.t.x, m.u.x, m.v.x);
-    bool const v2 = mt_valid(m.det.y, m.t.y, m.u.y, m.v.y);
-    if (doC && v1 && m.t.x < bt) {  // strict <: lowest index wins ties (megakernel.cu:126)
-      bt = m.t.x;
-      bestTri = int(i);
-      bu = m.u.x;
-      bv = m.v.x;
-    }
-    if (doS && v2 && m.t.y < st.smax) occluded = true;  // :210-211
-    cur = nxt;
+    DMT_TRI_TEST(a, i);
+    if (++i >= n) break;
+    uint32_t const ia = i + 1 < last ? i + 1 : last;
+    DMT_TRI_LOAD(a, ia);
+    __builtin_amdgcn_sched_barrier(0);
+    DMT_TRI_TEST(b, i);
+    ++i;
   }
+  bestTri = h.tri, bu = h.bu, bv = h.bv, occluded = h.occluded;
 }
 
-// BVH flavour of the pass: closest-hit traversal for the path ray, then any-hit traversal for the
-// pending shadow ray.  Results are identical to trace_pair_brute (same triangle test, same tie rule).
 struct LaneStats {  // stats build only
   uint32_t samples = 0, closest = 0, shadow = 0, bounces = 0;
   TraversalCounters tc;
 };
 template <bool STATS = false>
-DMT_DEV void trace_pair_bvh(BvhView const& bvh, PathState const& st, bool doC, bool doS, uint32_t gtid,
-                            int& bestTri, float& bu, float& bv, bool& occluded, LaneStats* ls = nullptr) {
+DMT_DEV void trace_pair_bvh(KArgs k, PathState const& st, bool doC, bool doS, uint32_t gtid, int& bestTri,
+                            float& bu, float& bv, bool& occluded, LaneStats* ls = nullptr) {
+  BvhView const bvh = load_bvh(k);
   float bt;
   if constexpr (STATS) ls->closest += doC ? 1u : 0u, ls->shadow += doS ? 1u : 0u;
   bvh_closest<STATS>(bvh, doC, mk3(st.rp.ox.x, st.rp.oy.x, st.rp.oz.x), mk3(st.rp.dx.x, st.rp.dy.x, st.rp.dz.x),
@@ -234,18 +287,17 @@ DMT_DEV void trace_pair_bvh(BvhView const& bvh, PathState const& st, bool doC, b
 // One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
 // sink(L) is called once per completed sample, in sample order.
 template <bool BVH, bool STATS = false, class Sink>
-DMT_DEV void lane_step(SceneView const& sc, BvhView const& bvh, uint32_t gtid, int maxDepth, PathState& st,
-                       Sink&& sink, LaneStats* ls = nullptr) {
+DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneStats* ls = nullptr) {
   bool const doC = st.active;
   bool const doS = st.hasShadow;
   int bestTri;
   float bu, bv;
   bool occluded;
   if constexpr (BVH)
-    trace_pair_bvh<STATS>(bvh, st, doC, doS, gtid, bestTri, bu, bv, occluded, ls);
+    trace_pair_bvh<STATS>(k, st, doC, doS, gtid, bestTri, bu, bv, occluded, ls);
   else
-    trace_pair_brute(sc, st, doC, doS, bestTri, bu, bv, occluded);
-  if constexpr (STATS) ls->bounces += (doC && bestTri >= 0 && st.depth < maxDepth) ? 1u : 0u;
+    trace_pair_brute(k, st, doC, doS, bestTri, bu, bv, occluded);
+  if constexpr (STATS) ls->bounces += (doC && bestTri >= 0 && st.depth < kargs(k)->maxDepth) ? 1u : 0u;
   if (doS) {
     st.hasShadow = false;
     if (st.finPending) {  // the shadow ray of an already finished sample
@@ -258,7 +310,7 @@ DMT_DEV void lane_step(SceneView const& sc, BvhView const& bvh, uint32_t gtid, i
     }
   }
   if (doC) {
-    if (path_shade(sc, maxDepth, st, bestTri, bu, bv)) {
+    if (path_shade(k, st, bestTri, bu, bv)) {
       st.active = false;
       if (st.hasShadow) {  // last NEE still untraced: park the sample, the lane may start the next
         put_Lfin(st.L);
@@ -281,8 +333,28 @@ __shared__ float s_prep[14 * kLdsThreads];
 // LDS moves) and the preparation of the following one is batched: it runs when at least half the wave
 // needs one, or when some lane would otherwise starve.  Sample values are pure functions of
 // (pixel, sample), so preparing early changes nothing.
-DMT_DEV void prepare_sample(CameraXf const& cam, SamplerParams const& sp, int px, int py, int32_t pixBase,
-                            uint32_t s) {
+// Cold kernel arguments (camera matrices, sampler parameters: 38 dwords) are only needed here, once per
+// sample.  Left to itself the compiler hoists their kernarg loads to the top of the kernel and keeps
+// them in SGPRs across the triangle loop, which overflows the SGPR file and spills INTO the hot loop.
+// Reading them through an opaque copy of the kernarg pointer keeps the s_loads at the point of use.
+struct ColdArgs {
+  CameraXf cam;
+  SamplerParams sp;
+};
+DMT_DEV ColdArgs load_cold_args(KArgs Pk) {
+  Pk = kargs(Pk);
+  ColdArgs c;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.cam.cfr[i] = Pk->cam.cfr[i], c.cam.rfc[i] = Pk->cam.rfc[i];
+  c.sp.scale0 = Pk->sp.scale0, c.sp.scale1 = Pk->sp.scale1, c.sp.exp0 = Pk->sp.exp0, c.sp.exp1 = Pk->sp.exp1;
+  c.sp.inv0 = Pk->sp.inv0, c.sp.inv1 = Pk->sp.inv1;
+  return c;
+}
+
+DMT_DEV void prepare_sample(KArgs Pk, int px, int py, int32_t pixBase, uint32_t s) {
+  ColdArgs const cold = load_cold_args(Pk);
+  CameraXf const& cam = cold.cam;
+  SamplerParams const& sp = cold.sp;
   float* const prep = s_prep + threadIdx.x;
   int32_t const hidx = pixBase + int32_t(s) * (sp.scale0 * sp.scale1);
   sampler_values(uint32_t(hidx), prep);
@@ -314,39 +386,58 @@ DMT_DEV void path_begin_prepared(PathState& st) {
 #ifndef DMT_PREP_THRESHOLD
 #define DMT_PREP_THRESHOLD 64
 #endif
+struct TileArgs {  // what a wave needs when it picks up a new work item
+  float4* mean;
+  float4* m2;
+  uint32_t* counter;
+  int width, x0, y0, x1, y1, tx0, ty0, rtx;
+  uint32_t numItems, sampleOffset, spp;
+  int rank, world;
+};
+DMT_DEV TileArgs load_tile_args(KArgs k) {
+  k = kargs(k);
+  TileArgs t;
+  t.mean = k->mean, t.m2 = k->m2, t.counter = k->counter, t.width = k->width;
+  t.x0 = k->x0, t.y0 = k->y0, t.x1 = k->x1, t.y1 = k->y1, t.tx0 = k->tx0, t.ty0 = k->ty0, t.rtx = k->rtx;
+  t.numItems = k->numItems, t.sampleOffset = k->sampleOffset, t.spp = k->spp, t.rank = k->rank, t.world = k->world;
+  return t;
+}
+
 template <bool BVH, bool STATS = false>
-DMT_DEV void megakernel_body(RenderParams const& P) {
+DMT_DEV void megakernel_body() {
+  KArgs const Pk = kargs_base();
   LaneStats ls;
   int const lane = int(threadIdx.x) & 63;
   uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
   float* const film = s_film + threadIdx.x;
   for (;;) {
+    TileArgs const T = load_tile_args(Pk);
     uint32_t item = 0;
-    if (lane == 0) item = atomicAdd(P.counter, 1u);
+    if (lane == 0) item = atomicAdd(T.counter, 1u);
     item = uint32_t(__builtin_amdgcn_readfirstlane(int(item)));
-    if (item >= P.numItems) break;
-    uint32_t const j = uint32_t(P.rank) + item * uint32_t(P.world);
-    int const tx = P.tx0 + int(j % uint32_t(P.rtx));
-    int const ty = P.ty0 + int(j / uint32_t(P.rtx));
+    if (item >= T.numItems) break;
+    uint32_t const j = uint32_t(T.rank) + item * uint32_t(T.world);
+    int const tx = T.tx0 + int(j % uint32_t(T.rtx));
+    int const ty = T.ty0 + int(j / uint32_t(T.rtx));
     int const px = tx * 8 + (lane & 7);
     int const py = ty * 8 + (lane >> 3);
-    bool const inside = px >= P.x0 && px < P.x1 && py >= P.y0 && py < P.y1;
-    size_t const pidx = size_t(px) + size_t(py) * size_t(P.width);
+    bool const inside = px >= T.x0 && px < T.x1 && py >= T.y0 && py < T.y1;
+    size_t const pidx = size_t(px) + size_t(py) * size_t(T.width);
 
     int32_t pixBase = 0;
     {  // SMEMLayout::startSample, T/megakernel/megakernel.cuh:45-57
       float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
       if (inside) {
-        m = P.mean[pidx];
-        v = P.m2[pidx];
-        pixBase = halton_pixel_base(P.sp, px, py);
+        m = T.mean[pidx];
+        v = T.m2[pidx];
+        pixBase = halton_pixel_base(load_cold_args(Pk).sp, px, py);
       }
       film[0 * kLdsThreads] = m.x, film[1 * kLdsThreads] = m.y, film[2 * kLdsThreads] = m.z;
       film[3 * kLdsThreads] = v.x, film[4 * kLdsThreads] = v.y, film[5 * kLdsThreads] = v.z;
       film[6 * kLdsThreads] = v.w;
     }
-    uint32_t sNext = P.sampleOffset;
-    uint32_t const sEnd = inside ? P.sampleOffset + P.spp : P.sampleOffset;
+    uint32_t sNext = T.sampleOffset;
+    uint32_t const sEnd = inside ? T.sampleOffset + T.spp : T.sampleOffset;
     PathState st{};
     auto welford = [&](f3 L) {  // SMEMLayout::updateSample, megakernel.cuh:59-79
       f3 mean = mk3(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads]);
@@ -360,12 +451,12 @@ DMT_DEV void megakernel_body(RenderParams const& P) {
       film[3 * kLdsThreads] = M2.x, film[4 * kLdsThreads] = M2.y, film[5 * kLdsThreads] = M2.z;
       film[6 * kLdsThreads] = N;
     };
-    uint32_t sPrep = P.sampleOffset;  // samples [sampleOffset, sPrep) have been prepared; sNext <= sPrep <= sNext + 1
+    uint32_t sPrep = sNext;  // samples [sampleOffset, sPrep) have been prepared; sNext <= sPrep <= sNext + 1
     for (;;) {
       bool const needPrep = sPrep == sNext && sPrep < sEnd;
       bool const starving = !st.active && needPrep;
       if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) {
-        if (needPrep) prepare_sample(P.cam, P.sp, px, py, pixBase, sPrep++);
+        if (needPrep) prepare_sample(Pk, px, py, pixBase, sPrep++);
       }
       if (!st.active && sNext < sPrep) {
         path_begin_prepared(st);
@@ -373,64 +464,75 @@ DMT_DEV void megakernel_body(RenderParams const& P) {
         if constexpr (STATS) ++ls.samples;
       }
       if (!__any(st.active || st.hasShadow)) break;
-      lane_step<BVH, STATS>(P.scene, P.bvh, gtid, P.maxDepth, st, welford, STATS ? &ls : nullptr);
+      lane_step<BVH, STATS>(Pk, gtid, st, welford, STATS ? &ls : nullptr);
     }
     if (inside) {  // endSample, megakernel.cuh:81-85
-      P.mean[pidx] = make_float4(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads], 0.f);
-      P.m2[pidx] = make_float4(film[3 * kLdsThreads], film[4 * kLdsThreads], film[5 * kLdsThreads],
-                               film[6 * kLdsThreads]);
+      TileArgs const T2 = load_tile_args(Pk);
+      T2.mean[pidx] = make_float4(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads], 0.f);
+      T2.m2[pidx] = make_float4(film[3 * kLdsThreads], film[4 * kLdsThreads], film[5 * kLdsThreads],
+                                film[6 * kLdsThreads]);
     }
   }
   if constexpr (STATS) {
-    atomicAdd(&P.stats[0], (unsigned long long)ls.samples);
-    atomicAdd(&P.stats[1], (unsigned long long)ls.closest);
-    atomicAdd(&P.stats[2], (unsigned long long)ls.shadow);
-    atomicAdd(&P.stats[3], (unsigned long long)ls.tc.nodes);
-    atomicAdd(&P.stats[4], (unsigned long long)ls.tc.tris);
-    atomicAdd(&P.stats[5], (unsigned long long)ls.bounces);
+    unsigned long long* const stats = kargs(Pk)->stats;
+    atomicAdd(&stats[0], (unsigned long long)ls.samples);
+    atomicAdd(&stats[1], (unsigned long long)ls.closest);
+    atomicAdd(&stats[2], (unsigned long long)ls.shadow);
+    atomicAdd(&stats[3], (unsigned long long)ls.tc.nodes);
+    atomicAdd(&stats[4], (unsigned long long)ls.tc.tris);
+    atomicAdd(&stats[5], (unsigned long long)ls.bounces);
   }
 }
 
 // brute force: the reference's semantics, every triangle tested (small scenes, parity mode)
-__global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD) k_megakernel(RenderParams P) { megakernel_body<false>(P); }
+__global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD) k_megakernel(RenderParams P) { megakernel_body<false>(); }
 // BVH traversal (large scenes); 16 KB more LDS per block for the traversal stacks
-__global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD_BVH) k_megakernel_bvh(RenderParams P) { megakernel_body<true>(P); }
+__global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD_BVH) k_megakernel_bvh(RenderParams P) { megakernel_body<true>(); }
 // same kernel with per-lane work counters (node visits, triangle tests, rays, bounces): feeds the
 // algorithmic-bytes model of the BVH path; never on the timed path
-__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats(RenderParams P) { megakernel_body<true, true>(P); }
+__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats(RenderParams P) { megakernel_body<true, true>(); }
 
 // ---------------------------------------------------------------------------------------------
 // device unit-test kernels
 // ---------------------------------------------------------------------------------------------
-__global__ void k_test_trace(SceneView sc, BvhView bvh, bool useBvh, CameraXf cam, SamplerParams sp, int maxDepth,
-                             int n, int32_t const* pxs, int32_t const* pys, int32_t const* ss, float* L3) {
+__global__ void k_test_trace(RenderParams P, bool useBvh, int n, int32_t const* pxs, int32_t const* pys,
+                             int32_t const* ss, float* L3) {
+  KArgs const k = kargs_base();
   int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
   PathState st{};
-  if (i < n) path_begin(st, cam, sp, pxs[i], pys[i], halton_pixel_base(sp, pxs[i], pys[i]), uint32_t(ss[i]));
+  if (i < n) {
+    ColdArgs const c = load_cold_args(k);
+    path_begin(st, c.cam, c.sp, pxs[i], pys[i], halton_pixel_base(c.sp, pxs[i], pys[i]), uint32_t(ss[i]));
+  }
   auto store = [&](f3 L) { L3[3 * i] = L.x, L3[3 * i + 1] = L.y, L3[3 * i + 2] = L.z; };
   uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
   for (;;) {
     if (!__any(st.active || st.hasShadow)) break;
     if (useBvh)
-      lane_step<true>(sc, bvh, gtid, maxDepth, st, store);
+      lane_step<true>(k, gtid, st, store);
     else
-      lane_step<false>(sc, bvh, gtid, maxDepth, st, store);
+      lane_step<false>(k, gtid, st, store);
   }
 }
 
 // single path with a per-bounce log {tri, pos3, beta3, L3 (before shading), depth, dim}
-__global__ void k_test_trace_log(SceneView sc, CameraXf cam, SamplerParams sp, int maxDepth, int px, int py,
-                                 int smp, float* rec12, int cap, int* nOut, float* L3) {
+__global__ void k_test_trace_log(RenderParams P, int px, int py, int smp, float* rec12, int cap, int* nOut,
+                                 float* L3) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  KArgs const k = kargs_base();
+  SceneView const sc = load_scene(k);
   PathState st{};
-  path_begin(st, cam, sp, px, py, halton_pixel_base(sp, px, py), uint32_t(smp));
+  {
+    ColdArgs const c = load_cold_args(k);
+    path_begin(st, c.cam, c.sp, px, py, halton_pixel_base(c.sp, px, py), uint32_t(smp));
+  }
   int n = 0;
   for (;;) {
     bool const doC = st.active, doS = st.hasShadow;
     int bestTri;
     float bu, bv;
     bool occluded;
-    trace_pair_brute(sc, st, doC, doS, bestTri, bu, bv, occluded);
+    trace_pair_brute(k, st, doC, doS, bestTri, bu, bv, occluded);
     if (doS) {
       if (!occluded) st.L = st.L + get_C();
       st.hasShadow = false;
@@ -445,7 +547,7 @@ __global__ void k_test_trace_log(SceneView sc, CameraXf cam, SamplerParams sp, i
         r[4] = st.beta.x, r[5] = st.beta.y, r[6] = st.beta.z, r[7] = st.L.x, r[8] = st.L.y, r[9] = st.L.z;
         r[10] = float(st.depth), r[11] = float(st.rng.dim);
       }
-      ended = path_shade(sc, maxDepth, st, bestTri, bu, bv);
+      ended = path_shade(k, st, bestTri, bu, bv);
       if (ended) st.active = false;
     }
     if (ended && !st.hasShadow) break;
@@ -551,8 +653,9 @@ __global__ void k_test_half(int n, float const* fin, uint16_t* hout, uint16_t co
   if (hin && fout) fout[i] = h2f(hin[i]);
 }
 
-__global__ void k_test_closest(SceneView sc, BvhView bvh, bool useBvh, int n, float const* o3, float const* d3,
-                               int32_t* tri, float* tOut) {
+__global__ void k_test_closest(RenderParams P, bool useBvh, int n, float const* o3, float const* d3, int32_t* tri,
+                               float* tOut) {
+  KArgs const k = kargs_base();
   int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
   bool const alive = i < n;
   PathState st{};
@@ -563,11 +666,11 @@ __global__ void k_test_closest(SceneView sc, BvhView bvh, bool useBvh, int n, fl
   float bu, bv, bt = kInf;
   bool occluded;
   if (useBvh)
-    trace_pair_bvh(bvh, st, alive, false, blockIdx.x * blockDim.x + threadIdx.x, best, bu, bv, occluded);
+    trace_pair_bvh(k, st, alive, false, blockIdx.x * blockDim.x + threadIdx.x, best, bu, bv, occluded);
   else
-    trace_pair_brute(sc, st, alive, false, best, bu, bv, occluded);
+    trace_pair_brute(k, st, alive, false, best, bu, bv, occluded);
   if (alive && best >= 0) {  // t of the winning triangle (same arithmetic as the loops)
-    TriS const T = load_tri(to_const_as(sc.tris), uint32_t(best));
+    TriS const T = load_tri(to_const_as(load_scene(k).tris), uint32_t(best));
     bt = mt_pair(T, st.rp).t.x;
   }
   if (alive) tri[i] = best, tOut[i] = bt;
@@ -716,6 +819,17 @@ BvhView bvhView(dmt_ctx const* c, size_t threads) {
   b.nodes = c->d_bvhNodes, b.tris = c->d_trisBvh, b.overflow = c->d_overflow;
   b.overflowStride = uint32_t(threads);
   return b;
+}
+
+// scene / camera / limits part of the argument struct (what the path-tracing device code reads)
+RenderParams baseParams(dmt_ctx const* c, size_t threads) {
+  RenderParams P{};
+  P.scene = sceneView(c);
+  P.bvh = bvhView(c, threads);
+  P.cam = c->xf;
+  P.sp = c->sp;
+  P.maxDepth = c->maxDepth;
+  return P;
 }
 
 template <class T>
@@ -1395,8 +1509,8 @@ int dmt_test_trace_samples(dmt_ctx* ctx, int n, const int32_t* pxs, const int32_
     int const rcO = ensureOverflow(ctx, threads);
     if (rcO) return rcO;
   }
-  hipLaunchKernelGGL(k_test_trace, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, sceneView(ctx), bvhView(ctx, threads),
-                     useBvh, ctx->xf, ctx->sp, ctx->maxDepth, n, dpx, dpy, dss, dL);
+  hipLaunchKernelGGL(k_test_trace, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, baseParams(ctx, threads), useBvh, n,
+                     dpx, dpy, dss, dL);
   int rc = finishTest(ctx);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpy(L3, dL, size_t(n) * 12, hipMemcpyDeviceToHost));
@@ -1415,8 +1529,8 @@ int dmt_test_trace_log(dmt_ctx* ctx, int px, int py, int s, float* rec12, int ca
   int* dn = S.up<int>(nullptr, 1);
   float* dL = S.up<float>(nullptr, 3);
   SCRATCH_CHECK(ctx, dr && dn && dL);
-  hipLaunchKernelGGL(k_test_trace_log, dim3(1), dim3(64), 0, ctx->stream, sceneView(ctx), ctx->xf, ctx->sp,
-                     ctx->maxDepth, px, py, s, dr, cap, dn, dL);
+  hipLaunchKernelGGL(k_test_trace_log, dim3(1), dim3(64), 0, ctx->stream, baseParams(ctx, 64), px, py, s, dr, cap, dn,
+                     dL);
   int rc = finishTest(ctx);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpy(rec12, dr, size_t(cap) * 48, hipMemcpyDeviceToHost));
@@ -1443,8 +1557,8 @@ int dmt_test_closest_hit(dmt_ctx* ctx, int nrays, const float* o3, const float* 
     int const rcO = ensureOverflow(ctx, threads);
     if (rcO) return rcO;
   }
-  hipLaunchKernelGGL(k_test_closest, dim3((nrays + 63) / 64), dim3(64), 0, ctx->stream, sceneView(ctx),
-                     bvhView(ctx, threads), useBvh, nrays, dO, dD, di, dt);
+  hipLaunchKernelGGL(k_test_closest, dim3((nrays + 63) / 64), dim3(64), 0, ctx->stream, baseParams(ctx, threads),
+                     useBvh, nrays, dO, dD, di, dt);
   int rc = finishTest(ctx);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpy(tri_index, di, size_t(nrays) * 4, hipMemcpyDeviceToHost));

@@ -403,20 +403,27 @@ DMT_DEV v2f fma_(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c
 DMT_DEV v2f fma_(v2f a, float b, v2f c) { return __builtin_elementwise_fma(a, v2f{b, b}, c); }
 DMT_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 DMT_DEV v2f rcp_(v2f x) { return v2f{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+// (the triangle is passed as nine scalars on purpose: handed over as a struct, LLVM keeps part of it in
+// a stack slot and "shuffles" its fields through scratch memory with overlapping <2 x float> accesses)
 template <class T>
-DMT_DEV void mt_core(TriS const& t, T ox, T oy, T oz, T dx, T dy, T dz, T& det, T& tt, T& u, T& v) {
-  T const cx = fma_(dy, t.e1z, -(dz * t.e1y));
-  T const cy = fma_(dz, t.e1x, -(dx * t.e1z));
-  T const cz = fma_(dx, t.e1y, -(dy * t.e1x));
-  det = fma_(cz, t.e0z, fma_(cy, t.e0y, cx * t.e0x));
+DMT_DEV void mt_core9(float p0x, float p0y, float p0z, float e0x, float e0y, float e0z, float e1x, float e1y,
+                      float e1z, T ox, T oy, T oz, T dx, T dy, T dz, T& det, T& tt, T& u, T& v) {
+  T const cx = fma_(dy, e1z, -(dz * e1y));
+  T const cy = fma_(dz, e1x, -(dx * e1z));
+  T const cz = fma_(dx, e1y, -(dy * e1x));
+  det = fma_(cz, e0z, fma_(cy, e0y, cx * e0x));
   T const inv = rcp_(det);
-  T const ovx = ox - t.p0x, ovy = oy - t.p0y, ovz = oz - t.p0z;
-  T const qx = fma_(ovy, t.e0z, -(ovz * t.e0y));
-  T const qy = fma_(ovz, t.e0x, -(ovx * t.e0z));
-  T const qz = fma_(ovx, t.e0y, -(ovy * t.e0x));
+  T const ovx = ox - p0x, ovy = oy - p0y, ovz = oz - p0z;
+  T const qx = fma_(ovy, e0z, -(ovz * e0y));
+  T const qy = fma_(ovz, e0x, -(ovx * e0z));
+  T const qz = fma_(ovx, e0y, -(ovy * e0x));
   u = inv * fma_(cz, ovz, fma_(cy, ovy, cx * ovx));
   v = inv * fma_(qz, dz, fma_(qy, dy, qx * dx));
-  tt = inv * fma_(qz, t.e1z, fma_(qy, t.e1y, qx * t.e1x));
+  tt = inv * fma_(qz, e1z, fma_(qy, e1y, qx * e1x));
+}
+template <class T>
+DMT_DEV void mt_core(TriS const& t, T ox, T oy, T oz, T dx, T dy, T dz, T& det, T& tt, T& u, T& v) {
+  mt_core9<T>(t.p0x, t.p0y, t.p0z, t.e0x, t.e0y, t.e0z, t.e1x, t.e1y, t.e1z, ox, oy, oz, dx, dy, dz, det, tt, u, v);
 }
 DMT_DEV MTPair mt_pair(TriS const& T, RayPair const& r) {
   MTPair m;
