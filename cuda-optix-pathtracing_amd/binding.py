@@ -51,7 +51,7 @@ def load_library():
 # every symbol include/dmt_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTED_SYMBOLS = [
     "dmt_ctx_create", "dmt_ctx_destroy", "dmt_last_error", "dmt_upload_triangles", "dmt_upload_bsdfs",
-    "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_partition",
+    "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_partition", "dmt_set_chunk",
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
     "dmt_render", "dmt_render_stats", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
     "dmt_test_sampler", "dmt_test_camera_rays", "dmt_test_bsdf", "dmt_test_light", "dmt_test_half",
@@ -158,6 +158,9 @@ class Renderer:
 
     def set_partition(self, rank, world):
         self._check(self._lib.dmt_set_partition(self._ctx, int(rank), int(world)), "dmt_set_partition")
+
+    def set_chunk(self, samples_per_item):
+        self._check(self._lib.dmt_set_chunk(self._ctx, C.c_uint32(samples_per_item)), "dmt_set_chunk")
 
     def set_stream(self, stream_ptr):
         self._check(self._lib.dmt_set_stream(self._ctx, C.c_void_p(stream_ptr)), "dmt_set_stream")

@@ -47,6 +47,10 @@ struct RenderParams {
   uint32_t numItems;      // owned tiles
   int rank, world;
   uint32_t sampleOffset, spp;
+  uint32_t chunkSpp;       // samples per work item
+  uint32_t numChunks;      // ceil(spp / chunkSpp)
+  uint32_t* tileDone;      // [numItems] chunks completed per owned tile (in-launch ordering of a tile's chunks)
+  uint32_t* errorFlag;     // set if a bounded wait gives up
   int maxDepth;
   unsigned long long* stats;  // stats build only: samples, closest rays, shadow rays, node visits, triangle tests, bounces
 };
@@ -391,7 +395,9 @@ struct TileArgs {  // what a wave needs when it picks up a new work item
   float4* m2;
   uint32_t* counter;
   int width, x0, y0, x1, y1, tx0, ty0, rtx;
-  uint32_t numItems, sampleOffset, spp;
+  uint32_t numItems, sampleOffset, spp, chunkSpp, numChunks;
+  uint32_t* tileDone;
+  uint32_t* errorFlag;
   int rank, world;
 };
 DMT_DEV TileArgs load_tile_args(KArgs k) {
@@ -400,6 +406,7 @@ DMT_DEV TileArgs load_tile_args(KArgs k) {
   t.mean = k->mean, t.m2 = k->m2, t.counter = k->counter, t.width = k->width;
   t.x0 = k->x0, t.y0 = k->y0, t.x1 = k->x1, t.y1 = k->y1, t.tx0 = k->tx0, t.ty0 = k->ty0, t.rtx = k->rtx;
   t.numItems = k->numItems, t.sampleOffset = k->sampleOffset, t.spp = k->spp, t.rank = k->rank, t.world = k->world;
+  t.chunkSpp = k->chunkSpp, t.numChunks = k->numChunks, t.tileDone = k->tileDone, t.errorFlag = k->errorFlag;
   return t;
 }
 
@@ -412,10 +419,33 @@ DMT_DEV void megakernel_body() {
   float* const film = s_film + threadIdx.x;
   for (;;) {
     TileArgs const T = load_tile_args(Pk);
-    uint32_t item = 0;
-    if (lane == 0) item = atomicAdd(T.counter, 1u);
-    item = uint32_t(__builtin_amdgcn_readfirstlane(int(item)));
-    if (item >= T.numItems) break;
+    // Work item = (sample chunk c, owned tile t), handed out chunk-major: all tiles of chunk 0, then
+    // chunk 1, ...  Small items keep the end-of-launch tail short (16 384 tiles over 4 096 resident waves
+    // would be 4 coarse items per wave).  A pixel's samples must still be folded in order, so chunk c of
+    // a tile may only start when chunk c-1 of the SAME tile is in the film: per-tile completion counter,
+    // release/acquire at agent scope.  Chunk c-1 was handed out numItems items earlier, so the wait is
+    // almost never taken; every wave of the grid is resident (persistent launch), so it cannot deadlock,
+    // and it is bounded anyway.
+    uint32_t work = 0;
+    if (lane == 0) work = atomicAdd(T.counter, 1u);
+    work = uint32_t(__builtin_amdgcn_readfirstlane(int(work)));
+    if (work >= T.numItems * T.numChunks) break;
+    uint32_t const chunk = work / T.numItems;
+    uint32_t const item = work - chunk * T.numItems;
+    if (chunk > 0) {
+      if (lane == 0) {
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&T.tileDone[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > (1u << 26)) {  // ~minutes: something is badly wrong, do not hang the GPU
+            __hip_atomic_store(T.errorFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     uint32_t const j = uint32_t(T.rank) + item * uint32_t(T.world);
     int const tx = T.tx0 + int(j % uint32_t(T.rtx));
     int const ty = T.ty0 + int(j / uint32_t(T.rtx));
@@ -436,8 +466,10 @@ DMT_DEV void megakernel_body() {
       film[3 * kLdsThreads] = v.x, film[4 * kLdsThreads] = v.y, film[5 * kLdsThreads] = v.z;
       film[6 * kLdsThreads] = v.w;
     }
-    uint32_t sNext = T.sampleOffset;
-    uint32_t const sEnd = inside ? T.sampleOffset + T.spp : T.sampleOffset;
+    uint32_t const s0 = T.sampleOffset + chunk * T.chunkSpp;
+    uint32_t const s1 = s0 + T.chunkSpp < T.sampleOffset + T.spp ? s0 + T.chunkSpp : T.sampleOffset + T.spp;
+    uint32_t sNext = s0;
+    uint32_t const sEnd = inside ? s1 : s0;
     PathState st{};
     auto welford = [&](f3 L) {  // SMEMLayout::updateSample, megakernel.cuh:59-79
       f3 mean = mk3(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads]);
@@ -471,6 +503,12 @@ DMT_DEV void megakernel_body() {
       T2.mean[pidx] = make_float4(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads], 0.f);
       T2.m2[pidx] = make_float4(film[3 * kLdsThreads], film[4 * kLdsThreads], film[5 * kLdsThreads],
                                 film[6 * kLdsThreads]);
+    }
+    if (T.numChunks > 1) {  // publish: film stores -> release -> completion counter
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_store(&load_tile_args(Pk).tileDone[item], chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if constexpr (STATS) {
@@ -715,7 +753,10 @@ struct dmt_ctx {
   float4* d_m2 = nullptr;
   bool ownFilm = false;
   int filmW = 0, filmH = 0;
-  uint32_t* d_counter = nullptr;
+  uint32_t* d_counter = nullptr;   // [0] work counter, [1] error flag
+  uint32_t* d_tileDone = nullptr;  // per owned tile: chunks completed (in-launch ordering)
+  size_t tileDoneCap = 0;
+  uint32_t chunkSpp = 128;         // samples per work item
   int maxDepth = 32;
   int accel = DMT_ACCEL_BRUTE_FORCE;
   int rank = 0, world = 1;
@@ -929,7 +970,8 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking);
   hipDeviceProp_t prop{};
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_ordinal);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counter), sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counter), 2 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(ctx->d_counter, 0, 2 * sizeof(uint32_t));
   int bpc = 0;
   if (e == hipSuccess)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, reinterpret_cast<void const*>(k_megakernel), 256, 0);
@@ -964,6 +1006,7 @@ int dmt_ctx_destroy(dmt_ctx* ctx) {
   (void)hipFree(ctx->d_lights);
   (void)hipFree(ctx->d_inf);
   (void)hipFree(ctx->d_counter);
+  (void)hipFree(ctx->d_tileDone);
   (void)hipFree(ctx->d_bvhNodes);
   (void)hipFree(ctx->d_trisBvh);
   (void)hipFree(ctx->d_overflow);
@@ -1196,9 +1239,21 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   P.sampleOffset = sample_offset, P.spp = spp;
   P.maxDepth = ctx->maxDepth;
   if (P.numItems == 0) return DMT_OK;
+  P.chunkSpp = ctx->chunkSpp ? ctx->chunkSpp : spp;
+  if (stats6) P.chunkSpp = spp;
+  P.numChunks = (spp + P.chunkSpp - 1) / P.chunkSpp;
+  if (uint64_t(P.numItems) * P.numChunks > 0x7FFFFFFFull) P.chunkSpp = spp, P.numChunks = 1;
+  if (size_t(P.numItems) > ctx->tileDoneCap) {
+    if (ctx->d_tileDone) (void)hipFree(ctx->d_tileDone);
+    ctx->d_tileDone = nullptr, ctx->tileDoneCap = 0;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_tileDone), size_t(P.numItems) * sizeof(uint32_t)));
+    ctx->tileDoneCap = P.numItems;
+  }
+  P.tileDone = ctx->d_tileDone;
+  P.errorFlag = ctx->d_counter + 1;
 
   bool const useBvh = ctx->accel == DMT_ACCEL_BVH;
-  uint32_t const wavesWanted = P.numItems;
+  uint32_t const wavesWanted = P.numItems * P.numChunks < P.numItems ? P.numItems : P.numItems * P.numChunks;
   uint32_t blocks = uint32_t(ctx->cuCount) * uint32_t(useBvh ? ctx->blocksPerCUBvh : ctx->blocksPerCU);
   uint32_t const blocksNeeded = (wavesWanted + 3) / 4;
   if (blocks > blocksNeeded) blocks = blocksNeeded;
@@ -1212,6 +1267,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   }
   auto& ev = ctx->events[ctx->eventsUsed];
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
+  if (P.numChunks > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->d_tileDone, 0, size_t(P.numItems) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
   if (useBvh) {
     if (!ctx->haveBvh) return fail(ctx, DMT_ERR_STATE, "dmt_render: BVH not built");
@@ -1308,6 +1364,18 @@ int dmt_sync(dmt_ctx* ctx) {
   if (!ctx) return DMT_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint32_t flag = 0;
+  HIP_TRY(ctx, hipMemcpy(&flag, ctx->d_counter + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (flag) {
+    (void)hipMemset(ctx->d_counter + 1, 0, sizeof(uint32_t));
+    return fail(ctx, DMT_ERR_HIP, "a wave gave up waiting for a tile's previous sample chunk (in-launch ordering)");
+  }
+  return DMT_OK;
+}
+
+int dmt_set_chunk(dmt_ctx* ctx, uint32_t samples_per_item) {
+  if (!ctx) return DMT_ERR_INVALID;
+  ctx->chunkSpp = samples_per_item;
   return DMT_OK;
 }
 
