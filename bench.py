@@ -233,8 +233,8 @@ def main():
             pmc = ROOT / "profiles" / "pmc_summary.json"
             if pmc.exists():
                 try:
-                    j = json.loads(pmc.read_text())
-                    if j.get("workload") == args.workload and j.get("kspp") == kspp:
+                    j = json.loads(pmc.read_text())["workloads"].get(args.workload)
+                    if j and j.get("kspp") == kspp:
                         traffic = j.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
