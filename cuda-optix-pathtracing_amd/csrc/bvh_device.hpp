@@ -179,4 +179,75 @@ DMT_DEV bool bvh_any(BvhView const& bv, bool active, f3 o, f3 d, float tmax, uin
   return occluded;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Resumable traversal: one step (one node, or one leaf) per call, so that the lanes of a wave can be at
+// different points of different traversals and nobody waits for the wave's longest ray.  A lane first
+// runs its closest-hit traversal, then (same stack) the any-hit traversal of its pending shadow ray.
+// Both phases share one code path (children are always distance-sorted) to keep divergence low.
+// ---------------------------------------------------------------------------------------------
+enum : int { TR_IDLE = 0, TR_CLOSEST = 1, TR_SHADOW = 2, TR_DONE = 3 };
+struct Traversal {
+  int phase;
+  bool doC, doS;     // what this round of the lane consists of
+  uint32_t cur;
+  BvhStack stack;
+  f3 o, d;           // ray of the current phase
+  SlabRay sr;
+  float tmax;        // closest: best t so far; shadow: light distance
+  int bestTri;       // ORIGINAL index
+  uint32_t bestOrig;
+  float bt, bu, bv;
+  bool occluded;
+};
+DMT_DEV void trav_set_ray(Traversal& tv, f3 o, f3 d) {
+  tv.o = o, tv.d = d;
+  tv.sr = slab_ray(o, d);
+  tv.cur = 0u;
+  tv.stack.sp = 0;
+}
+// node step: cur is an inner node
+template <bool STATS = false>
+DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
+  float const tlimit = tv.phase == TR_CLOSEST ? tv.bt : tv.tmax;
+  Bvh4Node const& n = bv.nodes[tv.cur];
+  if constexpr (STATS) ++tc->nodes;
+  float k0 = slab(tv.sr, n.minx[0], n.miny[0], n.minz[0], n.maxx[0], n.maxy[0], n.maxz[0], tlimit);
+  float k1 = slab(tv.sr, n.minx[1], n.miny[1], n.minz[1], n.maxx[1], n.maxy[1], n.maxz[1], tlimit);
+  float k2 = slab(tv.sr, n.minx[2], n.miny[2], n.minz[2], n.maxx[2], n.maxy[2], n.maxz[2], tlimit);
+  float k3 = slab(tv.sr, n.minx[3], n.miny[3], n.minz[3], n.maxx[3], n.maxy[3], n.maxz[3], tlimit);
+  uint32_t r0 = n.child[0], r1 = n.child[1], r2 = n.child[2], r3 = n.child[3];
+  k0 = r0 == kBvhEmpty ? kInf : k0, k1 = r1 == kBvhEmpty ? kInf : k1;
+  k2 = r2 == kBvhEmpty ? kInf : k2, k3 = r3 == kBvhEmpty ? kInf : k3;
+  cswap(k0, r0, k1, r1);
+  cswap(k2, r2, k3, r3);
+  cswap(k0, r0, k2, r2);
+  cswap(k1, r1, k3, r3);
+  cswap(k1, r1, k2, r2);
+  if (k3 < kInf) tv.stack.push(r3);
+  if (k2 < kInf) tv.stack.push(r2);
+  if (k1 < kInf) tv.stack.push(r1);
+  tv.cur = k0 < kInf ? r0 : tv.stack.pop();
+}
+// leaf step: cur is a leaf reference
+template <bool STATS = false>
+DMT_DEV void trav_leaf(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
+  bool const closest = tv.phase == TR_CLOSEST;
+  uint32_t const first = tv.cur & 0x0FFFFFFFu;
+  uint32_t const cnt = ((tv.cur >> 28) & 7u) + 1u;
+  if constexpr (STATS) tc->tris += cnt;
+  for (uint32_t j = 0; j < cnt; ++j) {
+    TriIsect const T = bv.tris[first + j];
+    float det, t, u, v;
+    mt_core<float>(tri_from(T), tv.o.x, tv.o.y, tv.o.z, tv.d.x, tv.d.y, tv.d.z, det, t, u, v);
+    bool const valid = mt_valid(det, t, u, v);
+    if (closest) {
+      if (valid && (t < tv.bt || (t == tv.bt && T.pad0 < tv.bestOrig)))
+        tv.bt = t, tv.bu = u, tv.bv = v, tv.bestOrig = T.pad0, tv.bestTri = int(T.pad0);
+    } else if (valid && t < tv.tmax) {
+      tv.occluded = true;
+    }
+  }
+  tv.cur = (!closest && tv.occluded) ? kBvhEmpty : tv.stack.pop();
+}
+
 }  // namespace dmt

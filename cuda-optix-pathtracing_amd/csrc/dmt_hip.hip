@@ -290,6 +290,10 @@ DMT_DEV void trace_pair_bvh(KArgs k, PathState const& st, bool doC, bool doS, ui
 
 // One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
 // sink(L) is called once per completed sample, in sample order.
+template <class Sink>
+DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
+                         Sink&& sink);
+
 template <bool BVH, bool STATS = false, class Sink>
 DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneStats* ls = nullptr) {
   bool const doC = st.active;
@@ -302,6 +306,13 @@ DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneS
   else
     trace_pair_brute(k, st, doC, doS, bestTri, bu, bv, occluded);
   if constexpr (STATS) ls->bounces += (doC && bestTri >= 0 && st.depth < kargs(k)->maxDepth) ? 1u : 0u;
+  lane_finish(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
+}
+
+// Second half of a ray pass: resolve the shadow ray (in the reference's accumulation order), then shade.
+template <class Sink>
+DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
+                         Sink&& sink) {
   if (doS) {
     st.hasShadow = false;
     if (st.finPending) {  // the shadow ray of an already finished sample
@@ -522,13 +533,173 @@ DMT_DEV void megakernel_body() {
   }
 }
 
+#ifndef DMT_BVH_SHADE_THRESHOLD
+#define DMT_BVH_SHADE_THRESHOLD 32
+#endif
+// BVH flavour of the megakernel.  Same items, same sample order, same film as megakernel_body, but the
+// traversal is asynchronous per lane (bvh_device.hpp: trav_step): every loop iteration advances each
+// traversing lane by one node or leaf, lanes that have finished both of their rays wait for shading, and
+// shading runs for all waiting lanes at once when at least DMT_BVH_SHADE_THRESHOLD of them are waiting (or
+// nobody is traversing).  Incoherent rays take very different numbers of steps; with a pass-synchronous
+// loop the wave ran at 14 % lane utilisation.
+template <bool STATS = false>
+DMT_DEV void megakernel_body_bvh() {
+  KArgs const Pk = kargs_base();
+  LaneStats ls;
+  int const lane = int(threadIdx.x) & 63;
+  uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  float* const film = s_film + threadIdx.x;
+  for (;;) {
+    TileArgs const T = load_tile_args(Pk);
+    uint32_t work = 0;
+    if (lane == 0) work = atomicAdd(T.counter, 1u);
+    work = uint32_t(__builtin_amdgcn_readfirstlane(int(work)));
+    if (work >= T.numItems * T.numChunks) break;
+    uint32_t const chunk = work / T.numItems;
+    uint32_t const item = work - chunk * T.numItems;
+    if (chunk > 0) {  // see megakernel_body
+      if (lane == 0) {
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&T.tileDone[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > (1u << 26)) {
+            __hip_atomic_store(T.errorFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    uint32_t const j = uint32_t(T.rank) + item * uint32_t(T.world);
+    int const tx = T.tx0 + int(j % uint32_t(T.rtx));
+    int const ty = T.ty0 + int(j / uint32_t(T.rtx));
+    int const px = tx * 8 + (lane & 7);
+    int const py = ty * 8 + (lane >> 3);
+    bool const inside = px >= T.x0 && px < T.x1 && py >= T.y0 && py < T.y1;
+    size_t const pidx = size_t(px) + size_t(py) * size_t(T.width);
+    int32_t pixBase = 0;
+    {
+      float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
+      if (inside) {
+        m = T.mean[pidx];
+        v = T.m2[pidx];
+        pixBase = halton_pixel_base(load_cold_args(Pk).sp, px, py);
+      }
+      film[0 * kLdsThreads] = m.x, film[1 * kLdsThreads] = m.y, film[2 * kLdsThreads] = m.z;
+      film[3 * kLdsThreads] = v.x, film[4 * kLdsThreads] = v.y, film[5 * kLdsThreads] = v.z;
+      film[6 * kLdsThreads] = v.w;
+    }
+    uint32_t const s0 = T.sampleOffset + chunk * T.chunkSpp;
+    uint32_t const s1 = s0 + T.chunkSpp < T.sampleOffset + T.spp ? s0 + T.chunkSpp : T.sampleOffset + T.spp;
+    uint32_t sNext = s0;
+    uint32_t const sEnd = inside ? s1 : s0;
+    PathState st{};
+    auto welford = [&](f3 L) {
+      f3 mean = mk3(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads]);
+      f3 M2 = mk3(film[3 * kLdsThreads], film[4 * kLdsThreads], film[5 * kLdsThreads]);
+      float const N = film[6 * kLdsThreads] + 1.0f;
+      f3 const delta = L - mean;
+      mean = mean + delta / N;
+      f3 const delta2 = L - mean;
+      M2 = M2 + delta * delta2;
+      film[0 * kLdsThreads] = mean.x, film[1 * kLdsThreads] = mean.y, film[2 * kLdsThreads] = mean.z;
+      film[3 * kLdsThreads] = M2.x, film[4 * kLdsThreads] = M2.y, film[5 * kLdsThreads] = M2.z;
+      film[6 * kLdsThreads] = N;
+    };
+    uint32_t sPrep = sNext;
+    Traversal tv{};
+    tv.phase = TR_IDLE;
+    BvhView const bvh0 = load_bvh(Pk);
+    tv.stack.ovf = bvh0.overflow + gtid;
+    tv.stack.stride = bvh0.overflowStride;
+    for (;;) {
+      // A. sample preparation / start (only lanes between rounds)
+      bool const idle = tv.phase == TR_IDLE;
+      bool const needPrep = sPrep == sNext && sPrep < sEnd;
+      bool const starving = idle && !st.active && needPrep;
+      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) {
+        if (needPrep) prepare_sample(Pk, px, py, pixBase, sPrep++);
+      }
+      if (idle && !st.active && sNext < sPrep) {
+        path_begin_prepared(st);
+        ++sNext;
+        if constexpr (STATS) ++ls.samples;
+      }
+      // B. start a round: closest-hit ray and/or pending shadow ray
+      if (idle && (st.active || st.hasShadow)) {
+        tv.doC = st.active, tv.doS = st.hasShadow;
+        tv.bt = kInf, tv.bestTri = -1, tv.bestOrig = 0xFFFFFFFFu, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false;
+        tv.tmax = st.smax;
+        if (tv.doC) {
+          tv.phase = TR_CLOSEST;
+          trav_set_ray(tv, mk3(st.rp.ox.x, st.rp.oy.x, st.rp.oz.x), mk3(st.rp.dx.x, st.rp.dy.x, st.rp.dz.x));
+        } else {
+          tv.phase = TR_SHADOW;
+          trav_set_ray(tv, mk3(st.rp.ox.y, st.rp.oy.y, st.rp.oz.y), mk3(st.rp.dx.y, st.rp.dy.y, st.rp.dz.y));
+        }
+        if constexpr (STATS) ls.closest += tv.doC ? 1u : 0u, ls.shadow += tv.doS ? 1u : 0u;
+      }
+      if (!__any(tv.phase != TR_IDLE)) break;
+      // C. traversal ("while-while"): run node steps until no traversing lane sits on an inner node, then
+      //    one leaf step for every lane sitting on a leaf; repeat until enough lanes wait for shading
+      BvhView const bvh = load_bvh(Pk);
+      for (;;) {
+        bool traversing = tv.phase == TR_CLOSEST || tv.phase == TR_SHADOW;
+        if (!__any(traversing)) break;
+        if (__popcll(__ballot(tv.phase == TR_DONE)) >= DMT_BVH_SHADE_THRESHOLD) break;
+        // inner nodes (kBvhEmpty has the leaf bit set, so finished lanes drop out by themselves)
+        while (__any(traversing && !(tv.cur & kBvhLeafFlag))) {
+          if (traversing && !(tv.cur & kBvhLeafFlag)) trav_node<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
+        }
+        if (traversing && tv.cur != kBvhEmpty) trav_leaf<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
+        if (traversing && tv.cur == kBvhEmpty) {
+          if (tv.phase == TR_CLOSEST && tv.doS) {
+            tv.phase = TR_SHADOW;
+            trav_set_ray(tv, mk3(st.rp.ox.y, st.rp.oy.y, st.rp.oz.y), mk3(st.rp.dx.y, st.rp.dy.y, st.rp.dz.y));
+          } else {
+            tv.phase = TR_DONE;
+          }
+        }
+      }
+      // D. resolve + shade every lane that has finished its round
+      if (tv.phase == TR_DONE) {
+        if constexpr (STATS) ls.bounces += (tv.doC && tv.bestTri >= 0 && st.depth < kargs(Pk)->maxDepth) ? 1u : 0u;
+        lane_finish(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, welford);
+        tv.phase = TR_IDLE;
+      }
+    }
+    if (inside) {
+      TileArgs const T2 = load_tile_args(Pk);
+      T2.mean[pidx] = make_float4(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads], 0.f);
+      T2.m2[pidx] = make_float4(film[3 * kLdsThreads], film[4 * kLdsThreads], film[5 * kLdsThreads],
+                                film[6 * kLdsThreads]);
+    }
+    if (T.numChunks > 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_store(&load_tile_args(Pk).tileDone[item], chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if constexpr (STATS) {
+    unsigned long long* const stats = kargs(Pk)->stats;
+    atomicAdd(&stats[0], (unsigned long long)ls.samples);
+    atomicAdd(&stats[1], (unsigned long long)ls.closest);
+    atomicAdd(&stats[2], (unsigned long long)ls.shadow);
+    atomicAdd(&stats[3], (unsigned long long)ls.tc.nodes);
+    atomicAdd(&stats[4], (unsigned long long)ls.tc.tris);
+    atomicAdd(&stats[5], (unsigned long long)ls.bounces);
+  }
+}
+
 // brute force: the reference's semantics, every triangle tested (small scenes, parity mode)
 __global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD) k_megakernel(RenderParams P) { megakernel_body<false>(); }
 // BVH traversal (large scenes); 16 KB more LDS per block for the traversal stacks
-__global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD_BVH) k_megakernel_bvh(RenderParams P) { megakernel_body<true>(); }
+__global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD_BVH) k_megakernel_bvh(RenderParams P) { megakernel_body_bvh<false>(); }
 // same kernel with per-lane work counters (node visits, triangle tests, rays, bounces): feeds the
 // algorithmic-bytes model of the BVH path; never on the timed path
-__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats(RenderParams P) { megakernel_body<true, true>(); }
+__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats(RenderParams P) { megakernel_body_bvh<true>(); }
 
 // ---------------------------------------------------------------------------------------------
 // device unit-test kernels
