@@ -502,3 +502,28 @@ def test_sample_chunking_is_bit_exact(renderer, O):
     for f in films[1:]:
         assert np.array_equal(films[0][0], f[0]) and np.array_equal(films[0][1], f[1])
     assert np.all(films[0][1][..., 3] == 96)
+
+
+def test_cli_writes_reference_named_pngs(renderer, O, tmp_path):
+    """The dmt-megakernel-compatible executable (host/main.cpp): same flags, same output names, and the
+    8-bit images equal the oracle film put through the reference's quantisation."""
+    import subprocess
+    from pathlib import Path
+    from PIL import Image
+    exe = Path(__file__).resolve().parent.parent / "cuda-optix-pathtracing_amd" / "host" / "dmt-megakernel-hip"
+    assert exe.exists(), "run __graft_entry__.build()"
+    out = subprocess.run([str(exe), "--width", "48", "--height", "40", "--spp", "12", "--kspp", "4", "--max-depth", "6",
+                          "--out", str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Parsed Configuration" in out.stdout and "Total Execution Time" in out.stdout
+    img = np.asarray(Image.open(tmp_path / "output-12.png").convert("RGB"))
+    se = np.asarray(Image.open(tmp_path / "output-12_sqrt_mse.png").convert("RGB"))
+    scene = O.cornell_box(48, 40)
+    mean, m2 = O.render(scene, 12, max_depth=6)
+    a, b = O.pixels_from_film(mean, m2)
+    assert img.shape == (40, 48, 3)
+    # 8-bit truncation: a float difference of 1e-6 can move a value across an integer boundary
+    assert (np.abs(img.astype(int) - a.astype(int)) <= 1).all() and (img != a).mean() < 0.01
+    assert (np.abs(se.astype(int) - b.astype(int)) <= 1).all() and (se != b).mean() < 0.02
+    bad = subprocess.run([str(exe), "--spp", "2", "--kspp", "4"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "invalid spp" in bad.stderr      # Config::validate (host_utils.cuh:48-51)
