@@ -49,6 +49,7 @@ struct RenderParams {
   uint32_t sampleOffset, spp;
   uint32_t chunkSpp;       // samples per work item
   uint32_t numChunks;      // ceil(spp / chunkSpp)
+  float* stage;            // per-wave staging of finished samples: [wave][chunkSpp][64] float3
   uint32_t* tileDone;      // [numItems] chunks completed per owned tile (in-launch ordering of a tile's chunks)
   uint32_t* errorFlag;     // set if a bounded wait gives up
   int maxDepth;
@@ -337,8 +338,6 @@ DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri
   }
 }
 
-// running film statistics of the lane's pixel, in LDS as [field][thread]: touched once per sample
-__shared__ float s_film[7 * kLdsThreads];
 // the lane's NEXT sample, prepared ahead of need (sampler values + camera ray), [field][thread]
 __shared__ float s_prep[14 * kLdsThreads];
 
@@ -398,6 +397,7 @@ DMT_DEV void path_begin_prepared(PathState& st) {
 #ifndef DMT_MIN_WAVES_PER_SIMD_BVH
 #define DMT_MIN_WAVES_PER_SIMD_BVH 3
 #endif
+constexpr uint32_t kMaxChunkSpp = 512;  // staging: 384 KB per wave at most
 #ifndef DMT_PREP_THRESHOLD
 #define DMT_PREP_THRESHOLD 64
 #endif
@@ -409,6 +409,7 @@ struct TileArgs {  // what a wave needs when it picks up a new work item
   uint32_t numItems, sampleOffset, spp, chunkSpp, numChunks;
   uint32_t* tileDone;
   uint32_t* errorFlag;
+  float* stage;
   int rank, world;
 };
 DMT_DEV TileArgs load_tile_args(KArgs k) {
@@ -417,111 +418,105 @@ DMT_DEV TileArgs load_tile_args(KArgs k) {
   t.mean = k->mean, t.m2 = k->m2, t.counter = k->counter, t.width = k->width;
   t.x0 = k->x0, t.y0 = k->y0, t.x1 = k->x1, t.y1 = k->y1, t.tx0 = k->tx0, t.ty0 = k->ty0, t.rtx = k->rtx;
   t.numItems = k->numItems, t.sampleOffset = k->sampleOffset, t.spp = k->spp, t.rank = k->rank, t.world = k->world;
-  t.chunkSpp = k->chunkSpp, t.numChunks = k->numChunks, t.tileDone = k->tileDone, t.errorFlag = k->errorFlag;
+  t.chunkSpp = k->chunkSpp, t.numChunks = k->numChunks, t.tileDone = k->tileDone, t.errorFlag = k->errorFlag, t.stage = k->stage;
   return t;
 }
 
-template <bool BVH, bool STATS = false>
-DMT_DEV void megakernel_body() {
-  KArgs const Pk = kargs_base();
-  LaneStats ls;
-  int const lane = int(threadIdx.x) & 63;
-  uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  float* const film = s_film + threadIdx.x;
-  for (;;) {
-    TileArgs const T = load_tile_args(Pk);
-    // Work item = (sample chunk c, owned tile t), handed out chunk-major: all tiles of chunk 0, then
-    // chunk 1, ...  Small items keep the end-of-launch tail short (16 384 tiles over 4 096 resident waves
-    // would be 4 coarse items per wave).  A pixel's samples must still be folded in order, so chunk c of
-    // a tile may only start when chunk c-1 of the SAME tile is in the film: per-tile completion counter,
-    // release/acquire at agent scope.  Chunk c-1 was handed out numItems items earlier, so the wait is
-    // almost never taken; every wave of the grid is resident (persistent launch), so it cannot deadlock,
-    // and it is bounded anyway.
-    uint32_t work = 0;
-    if (lane == 0) work = atomicAdd(T.counter, 1u);
-    work = uint32_t(__builtin_amdgcn_readfirstlane(int(work)));
-    if (work >= T.numItems * T.numChunks) break;
-    uint32_t const chunk = work / T.numItems;
-    uint32_t const item = work - chunk * T.numItems;
-    if (chunk > 0) {
-      if (lane == 0) {
-        uint32_t spins = 0;
-        while (__hip_atomic_load(&T.tileDone[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
-          __builtin_amdgcn_s_sleep(16);
-          if (++spins > (1u << 26)) {  // ~minutes: something is badly wrong, do not hang the GPU
-            __hip_atomic_store(T.errorFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
+// ---- work items ------------------------------------------------------------------------------------
+// Work item = (sample chunk c, owned tile t), handed out chunk-major from one atomic counter: all tiles
+// of chunk 0, then chunk 1, ...  A lane traces the chunk's samples of ITS pixel back to back (path
+// regeneration) and writes each finished sample's radiance to the wave's staging area in global memory
+// ([sample][lane] float3: 768 contiguous bytes per sample index).  When the wave has traced the whole
+// chunk it FOLDS it: waits until chunk c-1 of the same tile is in the film (per-tile completion counter,
+// acquire at agent scope), reads the pixel's running (mean, M2, N), applies the reference's Welford update
+// (SMEMLayout::updateSample, T/megakernel/megakernel.cuh:59-79) to the staged samples in index order,
+// writes the film and publishes c (release).  The film is therefore bit-identical for every chunk size
+// and schedule, but -- unlike folding while tracing -- chunks c and c+1 of one tile are traced
+// CONCURRENTLY by different waves: a small frame, or one GPU's share of a frame split eight ways
+// (2 048 tiles for 4 096 resident waves), still fills the machine.  Chunk c-1 was handed out before chunk
+// c and every wave of the grid is resident (persistent launch), so the wait cannot deadlock; it is
+// bounded anyway.  Cost: 12 B written + 12 B read per sample, against ~10^4 instructions to trace one.
+struct Item {
+  uint32_t chunk, item;
+  int px, py;
+  bool inside;
+  int32_t pixBase;
+  uint32_t s0, s1;
+  float* stage;  // wave-uniform base of the staging area
+};
+
+DMT_DEV bool item_next(KArgs Pk, int lane, uint32_t gtid, Item& it) {
+  TileArgs const T = load_tile_args(Pk);
+  uint32_t work = 0;
+  if (lane == 0) work = atomicAdd(T.counter, 1u);
+  work = uint32_t(__builtin_amdgcn_readfirstlane(int(work)));
+  if (work >= T.numItems * T.numChunks) return false;
+  it.chunk = work / T.numItems;
+  it.item = work - it.chunk * T.numItems;
+  uint32_t const j = uint32_t(T.rank) + it.item * uint32_t(T.world);
+  int const tx = T.tx0 + int(j % uint32_t(T.rtx));
+  int const ty = T.ty0 + int(j / uint32_t(T.rtx));
+  it.px = tx * 8 + (lane & 7);
+  it.py = ty * 8 + (lane >> 3);
+  it.inside = it.px >= T.x0 && it.px < T.x1 && it.py >= T.y0 && it.py < T.y1;
+  it.pixBase = it.inside ? halton_pixel_base(load_cold_args(Pk).sp, it.px, it.py) : 0;
+  it.s0 = T.sampleOffset + it.chunk * T.chunkSpp;
+  it.s1 = it.s0 + T.chunkSpp < T.sampleOffset + T.spp ? it.s0 + T.chunkSpp : T.sampleOffset + T.spp;
+  uint32_t const wave = uint32_t(__builtin_amdgcn_readfirstlane(int(gtid >> 6)));
+  it.stage = T.stage + size_t(wave) * size_t(T.chunkSpp) * 192u;
+  return true;
+}
+
+DMT_DEV void stage_sample(Item const& it, int lane, uint32_t k, f3 L) {
+  float* const p = it.stage + (k * 192u + uint32_t(lane) * 3u);
+  p[0] = L.x, p[1] = L.y, p[2] = L.z;
+}
+
+DMT_DEV void item_fold(KArgs Pk, int lane, Item const& it) {
+  TileArgs const T = load_tile_args(Pk);
+  if (it.chunk > 0) {
+    if (lane == 0) {
+      uint32_t spins = 0;
+      while (__hip_atomic_load(&T.tileDone[it.item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it.chunk) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 26)) {  // ~minutes: something is badly wrong, do not hang the GPU
+          __hip_atomic_store(T.errorFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    uint32_t const j = uint32_t(T.rank) + item * uint32_t(T.world);
-    int const tx = T.tx0 + int(j % uint32_t(T.rtx));
-    int const ty = T.ty0 + int(j / uint32_t(T.rtx));
-    int const px = tx * 8 + (lane & 7);
-    int const py = ty * 8 + (lane >> 3);
-    bool const inside = px >= T.x0 && px < T.x1 && py >= T.y0 && py < T.y1;
-    size_t const pidx = size_t(px) + size_t(py) * size_t(T.width);
-
-    int32_t pixBase = 0;
-    {  // SMEMLayout::startSample, T/megakernel/megakernel.cuh:45-57
-      float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
-      if (inside) {
-        m = T.mean[pidx];
-        v = T.m2[pidx];
-        pixBase = halton_pixel_base(load_cold_args(Pk).sp, px, py);
-      }
-      film[0 * kLdsThreads] = m.x, film[1 * kLdsThreads] = m.y, film[2 * kLdsThreads] = m.z;
-      film[3 * kLdsThreads] = v.x, film[4 * kLdsThreads] = v.y, film[5 * kLdsThreads] = v.z;
-      film[6 * kLdsThreads] = v.w;
-    }
-    uint32_t const s0 = T.sampleOffset + chunk * T.chunkSpp;
-    uint32_t const s1 = s0 + T.chunkSpp < T.sampleOffset + T.spp ? s0 + T.chunkSpp : T.sampleOffset + T.spp;
-    uint32_t sNext = s0;
-    uint32_t const sEnd = inside ? s1 : s0;
-    PathState st{};
-    auto welford = [&](f3 L) {  // SMEMLayout::updateSample, megakernel.cuh:59-79
-      f3 mean = mk3(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads]);
-      f3 M2 = mk3(film[3 * kLdsThreads], film[4 * kLdsThreads], film[5 * kLdsThreads]);
-      float const N = film[6 * kLdsThreads] + 1.0f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own staging stores (and the acquire) have landed
+  if (it.inside) {
+    size_t const pidx = size_t(it.px) + size_t(it.py) * size_t(T.width);
+    float4 const m = T.mean[pidx];  // SMEMLayout::startSample, megakernel.cuh:45-57
+    float4 const v = T.m2[pidx];
+    f3 mean = mk3(m.x, m.y, m.z), M2 = mk3(v.x, v.y, v.z);
+    float N = v.w;
+    uint32_t const n = it.s1 - it.s0;
+    float const* p = it.stage + uint32_t(lane) * 3u;
+#pragma unroll 8
+    for (uint32_t k = 0; k < n; ++k, p += 192) {  // SMEMLayout::updateSample, megakernel.cuh:59-79
+      f3 const L = mk3(p[0], p[1], p[2]);
+      N = N + 1.0f;
       f3 const delta = L - mean;
       mean = mean + delta / N;
       f3 const delta2 = L - mean;
       M2 = M2 + delta * delta2;
-      film[0 * kLdsThreads] = mean.x, film[1 * kLdsThreads] = mean.y, film[2 * kLdsThreads] = mean.z;
-      film[3 * kLdsThreads] = M2.x, film[4 * kLdsThreads] = M2.y, film[5 * kLdsThreads] = M2.z;
-      film[6 * kLdsThreads] = N;
-    };
-    uint32_t sPrep = sNext;  // samples [sampleOffset, sPrep) have been prepared; sNext <= sPrep <= sNext + 1
-    for (;;) {
-      bool const needPrep = sPrep == sNext && sPrep < sEnd;
-      bool const starving = !st.active && needPrep;
-      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) {
-        if (needPrep) prepare_sample(Pk, px, py, pixBase, sPrep++);
-      }
-      if (!st.active && sNext < sPrep) {
-        path_begin_prepared(st);
-        ++sNext;
-        if constexpr (STATS) ++ls.samples;
-      }
-      if (!__any(st.active || st.hasShadow)) break;
-      lane_step<BVH, STATS>(Pk, gtid, st, welford, STATS ? &ls : nullptr);
     }
-    if (inside) {  // endSample, megakernel.cuh:81-85
-      TileArgs const T2 = load_tile_args(Pk);
-      T2.mean[pidx] = make_float4(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads], 0.f);
-      T2.m2[pidx] = make_float4(film[3 * kLdsThreads], film[4 * kLdsThreads], film[5 * kLdsThreads],
-                                film[6 * kLdsThreads]);
-    }
-    if (T.numChunks > 1) {  // publish: film stores -> release -> completion counter
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0)
-        __hip_atomic_store(&load_tile_args(Pk).tileDone[item], chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    T.mean[pidx] = make_float4(mean.x, mean.y, mean.z, 0.f);  // endSample, megakernel.cuh:81-85
+    T.m2[pidx] = make_float4(M2.x, M2.y, M2.z, N);
   }
+  if (T.numChunks > 1) {  // publish: film stores -> release -> completion counter
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&T.tileDone[it.item], it.chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <bool STATS>
+DMT_DEV void flush_stats(KArgs Pk, LaneStats const& ls) {
   if constexpr (STATS) {
     unsigned long long* const stats = kargs(Pk)->stats;
     atomicAdd(&stats[0], (unsigned long long)ls.samples);
@@ -531,6 +526,39 @@ DMT_DEV void megakernel_body() {
     atomicAdd(&stats[4], (unsigned long long)ls.tc.tris);
     atomicAdd(&stats[5], (unsigned long long)ls.bounces);
   }
+}
+
+template <bool BVH, bool STATS = false>
+DMT_DEV void megakernel_body() {
+  KArgs const Pk = kargs_base();
+  LaneStats ls;
+  int const lane = int(threadIdx.x) & 63;
+  uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  Item it;
+  while (item_next(Pk, lane, gtid, it)) {
+    uint32_t sNext = it.s0;
+    uint32_t const sEnd = it.inside ? it.s1 : it.s0;
+    uint32_t nDone = 0;
+    PathState st{};
+    auto sink = [&](f3 L) { stage_sample(it, lane, nDone++, L); };
+    uint32_t sPrep = sNext;  // samples [s0, sPrep) have been prepared; sNext <= sPrep <= sNext + 1
+    for (;;) {
+      bool const needPrep = sPrep == sNext && sPrep < sEnd;
+      bool const starving = !st.active && needPrep;
+      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) {
+        if (needPrep) prepare_sample(Pk, it.px, it.py, it.pixBase, sPrep++);
+      }
+      if (!st.active && sNext < sPrep) {
+        path_begin_prepared(st);
+        ++sNext;
+        if constexpr (STATS) ++ls.samples;
+      }
+      if (!__any(st.active || st.hasShadow)) break;
+      lane_step<BVH, STATS>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
+    }
+    item_fold(Pk, lane, it);
+  }
+  flush_stats<STATS>(Pk, ls);
 }
 
 #ifndef DMT_BVH_SHADE_THRESHOLD
@@ -548,65 +576,15 @@ DMT_DEV void megakernel_body_bvh() {
   LaneStats ls;
   int const lane = int(threadIdx.x) & 63;
   uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  float* const film = s_film + threadIdx.x;
-  for (;;) {
-    TileArgs const T = load_tile_args(Pk);
-    uint32_t work = 0;
-    if (lane == 0) work = atomicAdd(T.counter, 1u);
-    work = uint32_t(__builtin_amdgcn_readfirstlane(int(work)));
-    if (work >= T.numItems * T.numChunks) break;
-    uint32_t const chunk = work / T.numItems;
-    uint32_t const item = work - chunk * T.numItems;
-    if (chunk > 0) {  // see megakernel_body
-      if (lane == 0) {
-        uint32_t spins = 0;
-        while (__hip_atomic_load(&T.tileDone[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
-          __builtin_amdgcn_s_sleep(16);
-          if (++spins > (1u << 26)) {
-            __hip_atomic_store(T.errorFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    uint32_t const j = uint32_t(T.rank) + item * uint32_t(T.world);
-    int const tx = T.tx0 + int(j % uint32_t(T.rtx));
-    int const ty = T.ty0 + int(j / uint32_t(T.rtx));
-    int const px = tx * 8 + (lane & 7);
-    int const py = ty * 8 + (lane >> 3);
-    bool const inside = px >= T.x0 && px < T.x1 && py >= T.y0 && py < T.y1;
-    size_t const pidx = size_t(px) + size_t(py) * size_t(T.width);
-    int32_t pixBase = 0;
-    {
-      float4 m = make_float4(0, 0, 0, 0), v = make_float4(0, 0, 0, 0);
-      if (inside) {
-        m = T.mean[pidx];
-        v = T.m2[pidx];
-        pixBase = halton_pixel_base(load_cold_args(Pk).sp, px, py);
-      }
-      film[0 * kLdsThreads] = m.x, film[1 * kLdsThreads] = m.y, film[2 * kLdsThreads] = m.z;
-      film[3 * kLdsThreads] = v.x, film[4 * kLdsThreads] = v.y, film[5 * kLdsThreads] = v.z;
-      film[6 * kLdsThreads] = v.w;
-    }
-    uint32_t const s0 = T.sampleOffset + chunk * T.chunkSpp;
-    uint32_t const s1 = s0 + T.chunkSpp < T.sampleOffset + T.spp ? s0 + T.chunkSpp : T.sampleOffset + T.spp;
-    uint32_t sNext = s0;
-    uint32_t const sEnd = inside ? s1 : s0;
+  Item it;
+  while (item_next(Pk, lane, gtid, it)) {
+    int const px = it.px, py = it.py;
+    int32_t const pixBase = it.pixBase;
+    uint32_t sNext = it.s0;
+    uint32_t const sEnd = it.inside ? it.s1 : it.s0;
+    uint32_t nDone = 0;
     PathState st{};
-    auto welford = [&](f3 L) {
-      f3 mean = mk3(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads]);
-      f3 M2 = mk3(film[3 * kLdsThreads], film[4 * kLdsThreads], film[5 * kLdsThreads]);
-      float const N = film[6 * kLdsThreads] + 1.0f;
-      f3 const delta = L - mean;
-      mean = mean + delta / N;
-      f3 const delta2 = L - mean;
-      M2 = M2 + delta * delta2;
-      film[0 * kLdsThreads] = mean.x, film[1 * kLdsThreads] = mean.y, film[2 * kLdsThreads] = mean.z;
-      film[3 * kLdsThreads] = M2.x, film[4 * kLdsThreads] = M2.y, film[5 * kLdsThreads] = M2.z;
-      film[6 * kLdsThreads] = N;
-    };
+    auto welford = [&](f3 L) { stage_sample(it, lane, nDone++, L); };
     uint32_t sPrep = sNext;
     Traversal tv{};
     tv.phase = TR_IDLE;
@@ -669,28 +647,9 @@ DMT_DEV void megakernel_body_bvh() {
         tv.phase = TR_IDLE;
       }
     }
-    if (inside) {
-      TileArgs const T2 = load_tile_args(Pk);
-      T2.mean[pidx] = make_float4(film[0 * kLdsThreads], film[1 * kLdsThreads], film[2 * kLdsThreads], 0.f);
-      T2.m2[pidx] = make_float4(film[3 * kLdsThreads], film[4 * kLdsThreads], film[5 * kLdsThreads],
-                                film[6 * kLdsThreads]);
-    }
-    if (T.numChunks > 1) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0)
-        __hip_atomic_store(&load_tile_args(Pk).tileDone[item], chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    item_fold(Pk, lane, it);
   }
-  if constexpr (STATS) {
-    unsigned long long* const stats = kargs(Pk)->stats;
-    atomicAdd(&stats[0], (unsigned long long)ls.samples);
-    atomicAdd(&stats[1], (unsigned long long)ls.closest);
-    atomicAdd(&stats[2], (unsigned long long)ls.shadow);
-    atomicAdd(&stats[3], (unsigned long long)ls.tc.nodes);
-    atomicAdd(&stats[4], (unsigned long long)ls.tc.tris);
-    atomicAdd(&stats[5], (unsigned long long)ls.bounces);
-  }
+  flush_stats<STATS>(Pk, ls);
 }
 
 // brute force: the reference's semantics, every triangle tested (small scenes, parity mode)
@@ -926,6 +885,8 @@ struct dmt_ctx {
   int filmW = 0, filmH = 0;
   uint32_t* d_counter = nullptr;   // [0] work counter, [1] error flag
   uint32_t* d_tileDone = nullptr;  // per owned tile: chunks completed (in-launch ordering)
+  float* d_stage = nullptr;        // staging of finished samples, [wave][chunkSpp][64] float3
+  size_t stageFloats = 0;
   size_t tileDoneCap = 0;
   uint32_t chunkSpp = 128;         // samples per work item
   int maxDepth = 32;
@@ -1178,6 +1139,7 @@ int dmt_ctx_destroy(dmt_ctx* ctx) {
   (void)hipFree(ctx->d_inf);
   (void)hipFree(ctx->d_counter);
   (void)hipFree(ctx->d_tileDone);
+  (void)hipFree(ctx->d_stage);
   (void)hipFree(ctx->d_bvhNodes);
   (void)hipFree(ctx->d_trisBvh);
   (void)hipFree(ctx->d_overflow);
@@ -1410,10 +1372,13 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   P.sampleOffset = sample_offset, P.spp = spp;
   P.maxDepth = ctx->maxDepth;
   if (P.numItems == 0) return DMT_OK;
+  // samples per work item; bounded so the staging area (768 B per sample index per resident wave) stays small
   P.chunkSpp = ctx->chunkSpp ? ctx->chunkSpp : spp;
-  if (stats6) P.chunkSpp = spp;
+  if (P.chunkSpp > spp) P.chunkSpp = spp;
+  if (P.chunkSpp > kMaxChunkSpp) P.chunkSpp = kMaxChunkSpp;
   P.numChunks = (spp + P.chunkSpp - 1) / P.chunkSpp;
-  if (uint64_t(P.numItems) * P.numChunks > 0x7FFFFFFFull) P.chunkSpp = spp, P.numChunks = 1;
+  if (uint64_t(P.numItems) * P.numChunks > 0x7FFFFFFFull)
+    return fail(ctx, DMT_ERR_INVALID, "dmt_render: too many work items (tiles x sample chunks); raise dmt_set_chunk or split the pass");
   if (size_t(P.numItems) > ctx->tileDoneCap) {
     if (ctx->d_tileDone) (void)hipFree(ctx->d_tileDone);
     ctx->d_tileDone = nullptr, ctx->tileDoneCap = 0;
@@ -1437,6 +1402,16 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
     ctx->events.emplace_back(a, b);
   }
   auto& ev = ctx->events[ctx->eventsUsed];
+  {  // staging area of finished samples, one slab per wave of the launch
+    size_t const floats = size_t(blocks) * 4u * size_t(P.chunkSpp) * 192u;
+    if (floats > ctx->stageFloats) {
+      if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+      ctx->d_stage = nullptr, ctx->stageFloats = 0;
+      HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_stage), floats * sizeof(float)));
+      ctx->stageFloats = floats;
+    }
+    P.stage = ctx->d_stage;
+  }
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
   if (P.numChunks > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->d_tileDone, 0, size_t(P.numItems) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
