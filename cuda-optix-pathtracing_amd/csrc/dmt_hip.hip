@@ -49,7 +49,7 @@ struct RenderParams {
   uint32_t sampleOffset, spp;
   uint32_t chunkSpp;       // samples per work item
   uint32_t numChunks;      // ceil(spp / chunkSpp)
-  float* stage;            // per-wave staging of finished samples: [wave][chunkSpp][64] float3
+  float* stage;            // per-wave staging of finished samples: [wave][slot 0/1][chunkSpp][64] float3
   uint32_t* tileDone;      // [numItems] chunks completed per owned tile (in-launch ordering of a tile's chunks)
   uint32_t* errorFlag;     // set if a bounded wait gives up
   int maxDepth;
@@ -426,58 +426,121 @@ DMT_DEV TileArgs load_tile_args(KArgs k) {
 // Work item = (sample chunk c, owned tile t), handed out chunk-major from one atomic counter: all tiles
 // of chunk 0, then chunk 1, ...  A lane traces the chunk's samples of ITS pixel back to back (path
 // regeneration) and writes each finished sample's radiance to the wave's staging area in global memory
-// ([sample][lane] float3: 768 contiguous bytes per sample index).  When the wave has traced the whole
-// chunk it FOLDS it: waits until chunk c-1 of the same tile is in the film (per-tile completion counter,
-// acquire at agent scope), reads the pixel's running (mean, M2, N), applies the reference's Welford update
-// (SMEMLayout::updateSample, T/megakernel/megakernel.cuh:59-79) to the staged samples in index order,
-// writes the film and publishes c (release).  The film is therefore bit-identical for every chunk size
-// and schedule, but -- unlike folding while tracing -- chunks c and c+1 of one tile are traced
+// ([sample][lane] float3: 768 contiguous bytes per sample index).  When every lane has traced its share
+// the wave FOLDS the item: waits until chunk c-1 of the same tile is in the film (per-tile completion
+// counter, acquire at agent scope), reads the pixel's running (mean, M2, N), applies the reference's
+// Welford update (SMEMLayout::updateSample, T/megakernel/megakernel.cuh:59-79) to the staged samples in
+// index order, writes the film and publishes c (release).  The film is therefore bit-identical for every
+// chunk size and schedule, but -- unlike folding while tracing -- chunks c and c+1 of one tile are traced
 // CONCURRENTLY by different waves: a small frame, or one GPU's share of a frame split eight ways
-// (2 048 tiles for 4 096 resident waves), still fills the machine.  Chunk c-1 was handed out before chunk
-// c and every wave of the grid is resident (persistent launch), so the wait cannot deadlock; it is
-// bounded anyway.  Cost: 12 B written + 12 B read per sample, against ~10^4 instructions to trace one.
-struct Item {
-  uint32_t chunk, item;
-  int px, py;
-  bool inside;
-  int32_t pixBase;
-  uint32_t s0, s1;
-  float* stage;  // wave-uniform base of the staging area
+// (2 048 tiles for 4 096 resident waves), still fills the machine.  Cost: 12 B written + 12 B read per
+// sample, against ~10^4 instructions to trace one.
+//
+// A wave holds TWO live items (sequence numbers cur and cur+1, slots seq & 1).  A lane that has finished its
+// share of item cur moves on to item cur+1 at once instead of idling while the slowest path of the tile
+// drains; when no lane is left on cur the wave folds it (lane i folds pixel i, whatever lane i is tracing
+// meanwhile stays in its registers) and fetches item cur+2 into the freed slot.  Without this the drain
+// costs 2 % at 128 samples per item and 7 % at 32; with it small items are cheap, which is what keeps the
+// end-of-launch tail short when a frame is split over 8 GPUs.
+//
+// Deadlock freedom: a fold of item w waits only for the item of the same tile one chunk earlier, which has
+// a smaller work index; a wave folds its items in increasing index order; every index below a fetched one
+// has been fetched by a resident wave (persistent launch).  So waits always point to strictly smaller
+// indices and the smallest live item waits for nothing.  The wait is bounded anyway.
+__shared__ uint32_t s_desc[kLdsThreads / 64][2][8];  // per wave, per slot: chunk, tile item, px0, py0, s0, n
+__shared__ int32_t s_pixbase[2 * kLdsThreads];       // per slot, per lane: Halton pixel base, -1 = outside the region
+
+struct LaneSched {
+  uint32_t seq = 0;      // item (wave-local sequence number) this lane is working on
+  uint32_t started = 0;  // samples of that item started
+  uint32_t nDone = 0;    // samples of that item staged
+  uint32_t quota = 0;    // samples of that item this lane has to trace (0 for pixels outside the region)
+  bool prepared = false; // the next sample is waiting in s_prep
 };
 
-DMT_DEV bool item_next(KArgs Pk, int lane, uint32_t gtid, Item& it) {
+DMT_DEV uint32_t lane_quota(uint32_t seq) {
+  uint32_t const slot = seq & 1u;
+  return s_pixbase[slot * kLdsThreads + threadIdx.x] >= 0 ? s_desc[threadIdx.x >> 6][slot][5] : 0u;
+}
+
+// fetch the next work item into slot seq & 1; false = the launch has no more items
+DMT_DEV bool item_fetch(KArgs Pk, int lane, uint32_t seq) {
   TileArgs const T = load_tile_args(Pk);
   uint32_t work = 0;
   if (lane == 0) work = atomicAdd(T.counter, 1u);
   work = uint32_t(__builtin_amdgcn_readfirstlane(int(work)));
   if (work >= T.numItems * T.numChunks) return false;
-  it.chunk = work / T.numItems;
-  it.item = work - it.chunk * T.numItems;
-  uint32_t const j = uint32_t(T.rank) + it.item * uint32_t(T.world);
-  int const tx = T.tx0 + int(j % uint32_t(T.rtx));
-  int const ty = T.ty0 + int(j / uint32_t(T.rtx));
-  it.px = tx * 8 + (lane & 7);
-  it.py = ty * 8 + (lane >> 3);
-  it.inside = it.px >= T.x0 && it.px < T.x1 && it.py >= T.y0 && it.py < T.y1;
-  it.pixBase = it.inside ? halton_pixel_base(load_cold_args(Pk).sp, it.px, it.py) : 0;
-  it.s0 = T.sampleOffset + it.chunk * T.chunkSpp;
-  it.s1 = it.s0 + T.chunkSpp < T.sampleOffset + T.spp ? it.s0 + T.chunkSpp : T.sampleOffset + T.spp;
-  uint32_t const wave = uint32_t(__builtin_amdgcn_readfirstlane(int(gtid >> 6)));
-  it.stage = T.stage + size_t(wave) * size_t(T.chunkSpp) * 192u;
+  uint32_t const chunk = work / T.numItems;
+  uint32_t const item = work - chunk * T.numItems;
+  uint32_t const j = uint32_t(T.rank) + item * uint32_t(T.world);
+  int const px0 = (T.tx0 + int(j % uint32_t(T.rtx))) * 8;
+  int const py0 = (T.ty0 + int(j / uint32_t(T.rtx))) * 8;
+  int const px = px0 + (lane & 7), py = py0 + (lane >> 3);
+  bool const inside = px >= T.x0 && px < T.x1 && py >= T.y0 && py < T.y1;
+  uint32_t const s0 = T.sampleOffset + chunk * T.chunkSpp;
+  uint32_t const s1 = s0 + T.chunkSpp < T.sampleOffset + T.spp ? s0 + T.chunkSpp : T.sampleOffset + T.spp;
+  uint32_t const slot = seq & 1u;
+  uint32_t* const d = s_desc[threadIdx.x >> 6][slot];  // wave-uniform values: every lane stores the same words
+  d[0] = chunk, d[1] = item, d[2] = uint32_t(px0), d[3] = uint32_t(py0), d[4] = s0, d[5] = s1 - s0;
+  s_pixbase[slot * kLdsThreads + threadIdx.x] = inside ? halton_pixel_base(load_cold_args(Pk).sp, px, py) : -1;
   return true;
 }
 
-DMT_DEV void stage_sample(Item const& it, int lane, uint32_t k, f3 L) {
-  float* const p = it.stage + (k * 192u + uint32_t(lane) * 3u);
-  p[0] = L.x, p[1] = L.y, p[2] = L.z;
+DMT_DEV float* stage_base(KArgs Pk, uint32_t gtid, uint32_t slot) {
+  KArgs const k = kargs(Pk);
+  uint32_t const wave = uint32_t(__builtin_amdgcn_readfirstlane(int(gtid >> 6)));
+  return k->stage + size_t(wave * 2u + slot) * size_t(k->chunkSpp) * 192u;
 }
 
-DMT_DEV void item_fold(KArgs Pk, int lane, Item const& it) {
+DMT_DEV void stage_sample(KArgs Pk, uint32_t gtid, int lane, LaneSched& Ls, f3 L) {
+  KArgs const k = kargs(Pk);
+  // per-lane slot: the two slabs of a wave are adjacent
+  float* const p = k->stage + (size_t((gtid >> 6) * 2u + (Ls.seq & 1u)) * size_t(k->chunkSpp) + Ls.nDone) * 192u + uint32_t(lane) * 3u;
+  p[0] = L.x, p[1] = L.y, p[2] = L.z;
+  ++Ls.nDone;
+}
+
+DMT_DEV void prepare_lane_sample(KArgs Pk, int lane, LaneSched& Ls) {
+  uint32_t const slot = Ls.seq & 1u;
+  uint32_t const* const d = s_desc[threadIdx.x >> 6][slot];
+  prepare_sample(Pk, int(d[2]) + (lane & 7), int(d[3]) + (lane >> 3), s_pixbase[slot * kLdsThreads + threadIdx.x],
+                 d[4] + Ls.started);
+  Ls.prepared = true;
+}
+
+// Film words that another wave of this launch may read or have written (the tile's previous / next chunk) are
+// moved with agent-scope relaxed atomics (global_load/store ... sc1: coherent across the XCDs' L2s) and
+// ordered against the completion counter by s_waitcnt.  The obvious alternative, plain accesses between
+// acquire/release FENCES, costs a buffer_inv / buffer_wbl2 of the XCD's whole L2 per item -- and the L2 is
+// full of dirty staging lines that nobody else will ever read.
+DMT_DEV float4 film_load(float4 const* p) {
+  unsigned long long const* const q = reinterpret_cast<unsigned long long const*>(p);
+  unsigned long long const a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long const b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float(uint32_t(a)), __uint_as_float(uint32_t(a >> 32)), __uint_as_float(uint32_t(b)),
+                     __uint_as_float(uint32_t(b >> 32)));
+}
+DMT_DEV void film_store(float4* p, float4 v) {
+  unsigned long long* const q = reinterpret_cast<unsigned long long*>(p);
+  __hip_atomic_store(q, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+DMT_DEV void item_fold(KArgs Pk, uint32_t gtid, int lane, uint32_t seq) {
   TileArgs const T = load_tile_args(Pk);
-  if (it.chunk > 0) {
+  uint32_t const slot = seq & 1u;
+  uint32_t const* const d = s_desc[threadIdx.x >> 6][slot];
+  uint32_t const chunk = uint32_t(__builtin_amdgcn_readfirstlane(int(d[0])));
+  uint32_t const item = uint32_t(__builtin_amdgcn_readfirstlane(int(d[1])));
+  uint32_t const n = uint32_t(__builtin_amdgcn_readfirstlane(int(d[5])));
+  int const px = int(d[2]) + (lane & 7), py = int(d[3]) + (lane >> 3);
+  bool const inside = s_pixbase[slot * kLdsThreads + threadIdx.x] >= 0;
+  if (chunk > 0) {
     if (lane == 0) {
       uint32_t spins = 0;
-      while (__hip_atomic_load(&T.tileDone[it.item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < it.chunk) {
+      while (__hip_atomic_load(&T.tileDone[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1u << 26)) {  // ~minutes: something is badly wrong, do not hang the GPU
           __hip_atomic_store(T.errorFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -485,17 +548,15 @@ DMT_DEV void item_fold(KArgs Pk, int lane, Item const& it) {
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own staging stores (and the acquire) have landed
-  if (it.inside) {
-    size_t const pidx = size_t(it.px) + size_t(it.py) * size_t(T.width);
-    float4 const m = T.mean[pidx];  // SMEMLayout::startSample, megakernel.cuh:45-57
-    float4 const v = T.m2[pidx];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // counter seen; own staging stores have landed
+  if (inside) {
+    size_t const pidx = size_t(px) + size_t(py) * size_t(T.width);
+    float4 const m = film_load(T.mean + pidx);  // SMEMLayout::startSample, megakernel.cuh:45-57
+    float4 const v = film_load(T.m2 + pidx);
     f3 mean = mk3(m.x, m.y, m.z), M2 = mk3(v.x, v.y, v.z);
     float N = v.w;
-    uint32_t const n = it.s1 - it.s0;
-    float const* p = it.stage + uint32_t(lane) * 3u;
+    float const* p = stage_base(Pk, gtid, slot) + uint32_t(lane) * 3u;
 #pragma unroll 8
     for (uint32_t k = 0; k < n; ++k, p += 192) {  // SMEMLayout::updateSample, megakernel.cuh:59-79
       f3 const L = mk3(p[0], p[1], p[2]);
@@ -505,14 +566,49 @@ DMT_DEV void item_fold(KArgs Pk, int lane, Item const& it) {
       f3 const delta2 = L - mean;
       M2 = M2 + delta * delta2;
     }
-    T.mean[pidx] = make_float4(mean.x, mean.y, mean.z, 0.f);  // endSample, megakernel.cuh:81-85
-    T.m2[pidx] = make_float4(M2.x, M2.y, M2.z, N);
+    film_store(T.mean + pidx, make_float4(mean.x, mean.y, mean.z, 0.f));  // endSample, megakernel.cuh:81-85
+    film_store(T.m2 + pidx, make_float4(M2.x, M2.y, M2.z, N));
   }
-  if (T.numChunks > 1) {  // publish: film stores -> release -> completion counter
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (T.numChunks > 1) {  // publish: film stores complete (written through) -> completion counter
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(&T.tileDone[it.item], it.chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&T.tileDone[item], chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// wave-level bookkeeping of the two live items
+struct WaveSched {
+  uint32_t cur = 0, fetched = 0;
+  bool exhausted = false;
+};
+DMT_DEV bool sched_begin(KArgs Pk, int lane, WaveSched& W, LaneSched& Ls) {
+  if (!item_fetch(Pk, lane, 0u)) return false;
+  W.fetched = 1;
+  Ls.quota = lane_quota(0u);
+  return true;
+}
+// a lane with nothing in flight and nothing left to start in its item moves on to the wave's next item
+// (fetched on demand, so that at the end of a launch no wave sits on an item it is not yet working on)
+DMT_DEV void sched_hop(KArgs Pk, int lane, WaveSched& W, LaneSched& Ls, bool laneIdle) {
+  bool const wantHop = laneIdle && Ls.started == Ls.quota;
+  if (!W.exhausted && W.fetched - W.cur < 2u && __any(wantHop && Ls.seq + 1u == W.fetched)) {
+    if (item_fetch(Pk, lane, W.fetched)) ++W.fetched;
+    else W.exhausted = true;
+  }
+  if (wantHop && Ls.seq + 1u < W.fetched) {
+    ++Ls.seq;
+    Ls.started = 0, Ls.nDone = 0, Ls.prepared = false;
+    Ls.quota = lane_quota(Ls.seq);
+  }
+}
+// item cur is complete when no lane is on it any more: fold it, fetch a new one; false = the wave is done
+DMT_DEV bool sched_retire(KArgs Pk, uint32_t gtid, int lane, WaveSched& W) {
+  item_fold(Pk, gtid, lane, W.cur);
+  ++W.cur;
+  if (W.cur == W.fetched && !W.exhausted) {
+    if (item_fetch(Pk, lane, W.fetched)) ++W.fetched;
+    else W.exhausted = true;
+  }
+  return W.cur != W.fetched;
 }
 
 template <bool STATS>
@@ -534,29 +630,30 @@ DMT_DEV void megakernel_body() {
   LaneStats ls;
   int const lane = int(threadIdx.x) & 63;
   uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  Item it;
-  while (item_next(Pk, lane, gtid, it)) {
-    uint32_t sNext = it.s0;
-    uint32_t const sEnd = it.inside ? it.s1 : it.s0;
-    uint32_t nDone = 0;
-    PathState st{};
-    auto sink = [&](f3 L) { stage_sample(it, lane, nDone++, L); };
-    uint32_t sPrep = sNext;  // samples [s0, sPrep) have been prepared; sNext <= sPrep <= sNext + 1
+  WaveSched W;
+  LaneSched Ls;
+  PathState st{};
+  auto sink = [&](f3 L) { stage_sample(Pk, gtid, lane, Ls, L); };
+  if (sched_begin(Pk, lane, W, Ls)) {
     for (;;) {
-      bool const needPrep = sPrep == sNext && sPrep < sEnd;
+      sched_hop(Pk, lane, W, Ls, !st.active && !st.hasShadow);
+      bool const needPrep = !Ls.prepared && Ls.started < Ls.quota;
       bool const starving = !st.active && needPrep;
       if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) {
-        if (needPrep) prepare_sample(Pk, it.px, it.py, it.pixBase, sPrep++);
+        if (needPrep) prepare_lane_sample(Pk, lane, Ls);
       }
-      if (!st.active && sNext < sPrep) {
+      if (!st.active && Ls.prepared) {
         path_begin_prepared(st);
-        ++sNext;
+        ++Ls.started, Ls.prepared = false;
         if constexpr (STATS) ++ls.samples;
       }
-      if (!__any(st.active || st.hasShadow)) break;
+      bool const busyCur = Ls.seq == W.cur && (st.active || st.hasShadow || Ls.started < Ls.quota);
+      if (!__any(busyCur)) {
+        if (!sched_retire(Pk, gtid, lane, W)) break;
+        continue;
+      }
       lane_step<BVH, STATS>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
     }
-    item_fold(Pk, lane, it);
   }
   flush_stats<STATS>(Pk, ls);
 }
@@ -576,32 +673,30 @@ DMT_DEV void megakernel_body_bvh() {
   LaneStats ls;
   int const lane = int(threadIdx.x) & 63;
   uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  Item it;
-  while (item_next(Pk, lane, gtid, it)) {
-    int const px = it.px, py = it.py;
-    int32_t const pixBase = it.pixBase;
-    uint32_t sNext = it.s0;
-    uint32_t const sEnd = it.inside ? it.s1 : it.s0;
-    uint32_t nDone = 0;
-    PathState st{};
-    auto welford = [&](f3 L) { stage_sample(it, lane, nDone++, L); };
-    uint32_t sPrep = sNext;
-    Traversal tv{};
-    tv.phase = TR_IDLE;
+  WaveSched W;
+  LaneSched Ls;
+  PathState st{};
+  auto sink = [&](f3 L) { stage_sample(Pk, gtid, lane, Ls, L); };
+  Traversal tv{};
+  tv.phase = TR_IDLE;
+  {
     BvhView const bvh0 = load_bvh(Pk);
     tv.stack.ovf = bvh0.overflow + gtid;
     tv.stack.stride = bvh0.overflowStride;
+  }
+  if (sched_begin(Pk, lane, W, Ls)) {
     for (;;) {
-      // A. sample preparation / start (only lanes between rounds)
+      // A. item hop, sample preparation / start (only lanes between rounds)
       bool const idle = tv.phase == TR_IDLE;
-      bool const needPrep = sPrep == sNext && sPrep < sEnd;
+      sched_hop(Pk, lane, W, Ls, idle && !st.active && !st.hasShadow);
+      bool const needPrep = !Ls.prepared && Ls.started < Ls.quota;
       bool const starving = idle && !st.active && needPrep;
       if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) {
-        if (needPrep) prepare_sample(Pk, px, py, pixBase, sPrep++);
+        if (needPrep) prepare_lane_sample(Pk, lane, Ls);
       }
-      if (idle && !st.active && sNext < sPrep) {
+      if (idle && !st.active && Ls.prepared) {
         path_begin_prepared(st);
-        ++sNext;
+        ++Ls.started, Ls.prepared = false;
         if constexpr (STATS) ++ls.samples;
       }
       // B. start a round: closest-hit ray and/or pending shadow ray
@@ -618,7 +713,12 @@ DMT_DEV void megakernel_body_bvh() {
         }
         if constexpr (STATS) ls.closest += tv.doC ? 1u : 0u, ls.shadow += tv.doS ? 1u : 0u;
       }
-      if (!__any(tv.phase != TR_IDLE)) break;
+      // R. the older live item is complete when no lane is on it any more
+      bool const busyCur = Ls.seq == W.cur && (tv.phase != TR_IDLE || Ls.started < Ls.quota);
+      if (!__any(busyCur)) {
+        if (!sched_retire(Pk, gtid, lane, W)) break;
+        continue;
+      }
       // C. traversal ("while-while"): run node steps until no traversing lane sits on an inner node, then
       //    one leaf step for every lane sitting on a leaf; repeat until enough lanes wait for shading
       BvhView const bvh = load_bvh(Pk);
@@ -643,11 +743,10 @@ DMT_DEV void megakernel_body_bvh() {
       // D. resolve + shade every lane that has finished its round
       if (tv.phase == TR_DONE) {
         if constexpr (STATS) ls.bounces += (tv.doC && tv.bestTri >= 0 && st.depth < kargs(Pk)->maxDepth) ? 1u : 0u;
-        lane_finish(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, welford);
+        lane_finish(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
         tv.phase = TR_IDLE;
       }
     }
-    item_fold(Pk, lane, it);
   }
   flush_stats<STATS>(Pk, ls);
 }
@@ -1403,7 +1502,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   }
   auto& ev = ctx->events[ctx->eventsUsed];
   {  // staging area of finished samples, one slab per wave of the launch
-    size_t const floats = size_t(blocks) * 4u * size_t(P.chunkSpp) * 192u;
+    size_t const floats = size_t(blocks) * 4u * 2u * size_t(P.chunkSpp) * 192u;
     if (floats > ctx->stageFloats) {
       if (ctx->d_stage) (void)hipFree(ctx->d_stage);
       ctx->d_stage = nullptr, ctx->stageFloats = 0;
