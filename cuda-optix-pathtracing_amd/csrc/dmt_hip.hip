@@ -99,10 +99,11 @@ struct PathState {
   bool finPending;  // the pending shadow ray belongs to the finished sample parked in Lfin
   float smax;
   Sampler rng;
+  uint32_t sidx;    // where the current sample's radiance goes (staging index, megakernel only)
 };
 // cold per-lane values in LDS, [field][thread]: pending NEE contribution C (0..2) and the parked
-// radiance Lfin of a finished sample (3..5); each is touched once per ray pass at most
-__shared__ float s_cold[6 * kLdsThreads];
+// radiance Lfin of a finished sample (3..5) with its staging index (6); each is touched once per ray pass at most
+__shared__ float s_cold[7 * kLdsThreads];
 DMT_DEV void put_C(f3 v) {
   float* const c = s_cold + threadIdx.x;
   c[0 * kLdsThreads] = v.x, c[1 * kLdsThreads] = v.y, c[2 * kLdsThreads] = v.z;
@@ -119,6 +120,8 @@ DMT_DEV f3 get_Lfin() {
   float const* const c = s_cold + threadIdx.x;
   return mk3(c[3 * kLdsThreads], c[4 * kLdsThreads], c[5 * kLdsThreads]);
 }
+DMT_DEV void put_finIdx(uint32_t i) { s_cold[6 * kLdsThreads + threadIdx.x] = __uint_as_float(i); }
+DMT_DEV uint32_t get_finIdx() { return __float_as_uint(s_cold[6 * kLdsThreads + threadIdx.x]); }
 DMT_DEV f3 ray_dir(PathState const& st) { return mk3(st.rp.dx.x, st.rp.dy.x, st.rp.dz.x); }
 DMT_DEV void set_ray(PathState& st, f3 o, f3 d) {
   st.rp.ox.x = o.x, st.rp.oy.x = o.y, st.rp.oz.x = o.z;
@@ -290,7 +293,7 @@ DMT_DEV void trace_pair_bvh(KArgs k, PathState const& st, bool doC, bool doS, ui
 }
 
 // One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
-// sink(L) is called once per completed sample, in sample order.
+// sink(L, sidx) is called once per completed sample with the index the sample was started with.
 template <class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink);
@@ -320,7 +323,7 @@ DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri
       f3 Lfin = get_Lfin();
       if (!occluded) Lfin = Lfin + get_C();
       st.finPending = false;
-      sink(Lfin);
+      sink(Lfin, get_finIdx());
     } else if (!occluded) {
       st.L = st.L + get_C();  // NEE of the previous bounce, added before anything of this bounce
     }
@@ -330,16 +333,17 @@ DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri
       st.active = false;
       if (st.hasShadow) {  // last NEE still untraced: park the sample, the lane may start the next
         put_Lfin(st.L);
+        put_finIdx(st.sidx);
         st.finPending = true;
       } else {
-        sink(st.L);
+        sink(st.L, st.sidx);
       }
     }
   }
 }
 
 // the lane's NEXT sample, prepared ahead of need (sampler values + camera ray), [field][thread]
-__shared__ float s_prep[14 * kLdsThreads];
+__shared__ float s_prep[15 * kLdsThreads];  // 0-7 sampler values, 8-13 camera ray, 14 staging index
 
 // Starting a sample costs ~2k instructions (8 scrambled radical inverses + camera ray).  Paths end at
 // different times, so doing it on demand would run that code for a handful of lanes on almost every
@@ -389,6 +393,7 @@ DMT_DEV void path_begin_prepared(PathState& st) {
   st.depth = 0;
   st.lastT = false;
   st.active = true;
+  st.sidx = __float_as_uint(prep[14 * kLdsThreads]);
 }
 
 #ifndef DMT_MIN_WAVES_PER_SIMD
@@ -424,47 +429,52 @@ DMT_DEV TileArgs load_tile_args(KArgs k) {
 
 // ---- work items ------------------------------------------------------------------------------------
 // Work item = (sample chunk c, owned tile t), handed out chunk-major from one atomic counter: all tiles
-// of chunk 0, then chunk 1, ...  A lane traces the chunk's samples of ITS pixel back to back (path
-// regeneration) and writes each finished sample's radiance to the wave's staging area in global memory
-// ([sample][lane] float3: 768 contiguous bytes per sample index).  When every lane has traced its share
-// the wave FOLDS the item: waits until chunk c-1 of the same tile is in the film (per-tile completion
-// counter, acquire at agent scope), reads the pixel's running (mean, M2, N), applies the reference's
-// Welford update (SMEMLayout::updateSample, T/megakernel/megakernel.cuh:59-79) to the staged samples in
-// index order, writes the film and publishes c (release).  The film is therefore bit-identical for every
-// chunk size and schedule, but -- unlike folding while tracing -- chunks c and c+1 of one tile are traced
-// CONCURRENTLY by different waves: a small frame, or one GPU's share of a frame split eight ways
-// (2 048 tiles for 4 096 resident waves), still fills the machine.  Cost: 12 B written + 12 B read per
-// sample, against ~10^4 instructions to trace one.
+// of chunk 0, then chunk 1, ...  An item is n samples x 64 pixels = up to 64 n UNITS (pixel, sample).
 //
-// A wave holds TWO live items (sequence numbers cur and cur+1, slots seq & 1).  A lane that has finished its
-// share of item cur moves on to item cur+1 at once instead of idling while the slowest path of the tile
-// drains; when no lane is left on cur the wave folds it (lane i folds pixel i, whatever lane i is tracing
-// meanwhile stays in its registers) and fetches item cur+2 into the freed slot.  Without this the drain
-// costs 2 % at 128 samples per item and 7 % at 32; with it small items are cheap, which is what keeps the
-// end-of-launch tail short when a frame is split over 8 GPUs.
+// * Lanes are not tied to pixels.  A lane that needs work takes the item's next unit (wave-wide ballot +
+//   prefix count on a wave-uniform cursor; unit u -> pixel u mod 64, sample u div 64, so a batch of 64
+//   requests is one sample of every pixel).  Path lengths differ between pixels (glass vs wall) and between
+//   samples; with lane == pixel every item ran at the pace of its slowest pixel, now the wave stays full
+//   until the item runs out of units.
+// * A finished sample's radiance goes to the wave's staging area in global memory ([sample][pixel] float3,
+//   12 B written + 12 B read per sample against ~10^4 instructions to trace one).  When all units of an item
+//   are staged the wave FOLDS it: waits until chunk c-1 of the same tile is in the film (per-tile completion
+//   counter), reads the pixels' running (mean, M2, N), applies the reference's Welford update
+//   (SMEMLayout::updateSample, T/megakernel/megakernel.cuh:59-79) to the staged samples in index order,
+//   writes the film and publishes c.  The film is therefore bit-identical for every chunk size and schedule,
+//   and chunks c and c+1 of one tile are traced CONCURRENTLY by different waves: a small frame, or one GPU's
+//   share of a frame split eight ways (2 048 tiles for 4 096 resident waves), still fills the machine.
+// * A wave holds up to TWO live items (sequence numbers cur and cur+1, slots seq & 1): when item cur has no
+//   units left, free lanes draw from item cur+1 (fetched at that moment) while the last paths of cur drain;
+//   when cur's last sample is staged the wave folds it (lane i folds pixel i; whatever lane i is tracing
+//   meanwhile stays in its registers).  Small items are therefore cheap, which keeps the end-of-launch tail
+//   short when a frame is split over 8 GPUs.
 //
 // Deadlock freedom: a fold of item w waits only for the item of the same tile one chunk earlier, which has
 // a smaller work index; a wave folds its items in increasing index order; every index below a fetched one
 // has been fetched by a resident wave (persistent launch).  So waits always point to strictly smaller
 // indices and the smallest live item waits for nothing.  The wait is bounded anyway.
-__shared__ uint32_t s_desc[kLdsThreads / 64][2][8];  // per wave, per slot: chunk, tile item, px0, py0, s0, n
-__shared__ int32_t s_pixbase[2 * kLdsThreads];       // per slot, per lane: Halton pixel base, -1 = outside the region
+__shared__ uint32_t s_desc[kLdsThreads / 64][2][8];  // per wave, per slot: chunk, tile item, px0, py0, s0, n, nInside
+__shared__ int32_t s_pixbase[2 * kLdsThreads];       // per slot, per pixel: Halton pixel base, -1 = outside the region
+__shared__ uint32_t s_pixmap[2 * kLdsThreads];       // per slot: j-th pixel inside the region
 
+constexpr uint32_t kSlotBit = 0x80000000u;  // staging index = slot bit | (sample * 64 + pixel)
+
+// wave-level bookkeeping (all wave-uniform)
+struct WaveSched {
+  uint32_t cur = 0, fetched = 0;          // live items are [cur, fetched), at most two
+  uint32_t alloc = 0;                     // item units are drawn from
+  uint32_t nextUnit = 0, totalUnits = 0;  // cursor / size of item `alloc`
+  bool exhausted = false;                 // the launch has no more items
+};
+// per-lane bookkeeping
 struct LaneSched {
-  uint32_t seq = 0;      // item (wave-local sequence number) this lane is working on
-  uint32_t started = 0;  // samples of that item started
-  uint32_t nDone = 0;    // samples of that item staged
-  uint32_t quota = 0;    // samples of that item this lane has to trace (0 for pixels outside the region)
-  bool prepared = false; // the next sample is waiting in s_prep
+  bool prepared = false;  // a unit is waiting in s_prep
+  bool prepSlot = false;  // ... of the item in this slot
 };
 
-DMT_DEV uint32_t lane_quota(uint32_t seq) {
-  uint32_t const slot = seq & 1u;
-  return s_pixbase[slot * kLdsThreads + threadIdx.x] >= 0 ? s_desc[threadIdx.x >> 6][slot][5] : 0u;
-}
-
 // fetch the next work item into slot seq & 1; false = the launch has no more items
-DMT_DEV bool item_fetch(KArgs Pk, int lane, uint32_t seq) {
+DMT_DEV bool item_fetch(KArgs Pk, int lane, uint32_t seq, uint32_t& units) {
   TileArgs const T = load_tile_args(Pk);
   uint32_t work = 0;
   if (lane == 0) work = atomicAdd(T.counter, 1u);
@@ -480,32 +490,39 @@ DMT_DEV bool item_fetch(KArgs Pk, int lane, uint32_t seq) {
   uint32_t const s0 = T.sampleOffset + chunk * T.chunkSpp;
   uint32_t const s1 = s0 + T.chunkSpp < T.sampleOffset + T.spp ? s0 + T.chunkSpp : T.sampleOffset + T.spp;
   uint32_t const slot = seq & 1u;
+  unsigned long long const insideMask = __ballot(inside);
+  uint32_t const nInside = uint32_t(__popcll(insideMask));
   uint32_t* const d = s_desc[threadIdx.x >> 6][slot];  // wave-uniform values: every lane stores the same words
-  d[0] = chunk, d[1] = item, d[2] = uint32_t(px0), d[3] = uint32_t(py0), d[4] = s0, d[5] = s1 - s0;
-  s_pixbase[slot * kLdsThreads + threadIdx.x] = inside ? halton_pixel_base(load_cold_args(Pk).sp, px, py) : -1;
+  d[0] = chunk, d[1] = item, d[2] = uint32_t(px0), d[3] = uint32_t(py0), d[4] = s0, d[5] = s1 - s0, d[6] = nInside;
+  uint32_t const wbase = slot * kLdsThreads + (threadIdx.x & ~63u);
+  s_pixbase[wbase + lane] = inside ? halton_pixel_base(load_cold_args(Pk).sp, px, py) : -1;
+  if (inside) s_pixmap[wbase + uint32_t(__popcll(insideMask & ((1ull << lane) - 1ull)))] = uint32_t(lane);
+  units = nInside * (s1 - s0);
   return true;
 }
 
-DMT_DEV float* stage_base(KArgs Pk, uint32_t gtid, uint32_t slot) {
+DMT_DEV float* stage_slab(KArgs Pk, uint32_t gtid, uint32_t slot) {
   KArgs const k = kargs(Pk);
-  uint32_t const wave = uint32_t(__builtin_amdgcn_readfirstlane(int(gtid >> 6)));
-  return k->stage + size_t(wave * 2u + slot) * size_t(k->chunkSpp) * 192u;
+  return k->stage + size_t((gtid >> 6) * 2u + slot) * size_t(k->chunkSpp) * 192u;
 }
-
-DMT_DEV void stage_sample(KArgs Pk, uint32_t gtid, int lane, LaneSched& Ls, f3 L) {
-  KArgs const k = kargs(Pk);
-  // per-lane slot: the two slabs of a wave are adjacent
-  float* const p = k->stage + (size_t((gtid >> 6) * 2u + (Ls.seq & 1u)) * size_t(k->chunkSpp) + Ls.nDone) * 192u + uint32_t(lane) * 3u;
+DMT_DEV void stage_sample(KArgs Pk, uint32_t gtid, uint32_t sidx, f3 L) {
+  float* const p = stage_slab(Pk, gtid, sidx >> 31) + size_t(sidx & ~kSlotBit) * 3u;
   p[0] = L.x, p[1] = L.y, p[2] = L.z;
-  ++Ls.nDone;
 }
 
-DMT_DEV void prepare_lane_sample(KArgs Pk, int lane, LaneSched& Ls) {
-  uint32_t const slot = Ls.seq & 1u;
+// prepare unit u of item `seq` in this lane's s_prep
+DMT_DEV void prepare_unit(KArgs Pk, uint32_t seq, uint32_t u, LaneSched& Ls) {
+  uint32_t const slot = seq & 1u;
   uint32_t const* const d = s_desc[threadIdx.x >> 6][slot];
-  prepare_sample(Pk, int(d[2]) + (lane & 7), int(d[3]) + (lane >> 3), s_pixbase[slot * kLdsThreads + threadIdx.x],
-                 d[4] + Ls.started);
-  Ls.prepared = true;
+  uint32_t const nInside = d[6];
+  uint32_t k, j;
+  if (nInside == 64u) k = u >> 6, j = u & 63u;
+  else k = u / nInside, j = u - k * nInside;
+  uint32_t const wbase = slot * kLdsThreads + (threadIdx.x & ~63u);
+  uint32_t const pixel = s_pixmap[wbase + j];
+  prepare_sample(Pk, int(d[2]) + int(pixel & 7u), int(d[3]) + int(pixel >> 3), s_pixbase[wbase + pixel], d[4] + k);
+  s_prep[14 * kLdsThreads + threadIdx.x] = __uint_as_float((slot << 31) | (k * 64u + pixel));
+  Ls.prepared = true, Ls.prepSlot = slot != 0u;
 }
 
 // Film words that another wave of this launch may read or have written (the tile's previous / next chunk) are
@@ -556,7 +573,7 @@ DMT_DEV void item_fold(KArgs Pk, uint32_t gtid, int lane, uint32_t seq) {
     float4 const v = film_load(T.m2 + pidx);
     f3 mean = mk3(m.x, m.y, m.z), M2 = mk3(v.x, v.y, v.z);
     float N = v.w;
-    float const* p = stage_base(Pk, gtid, slot) + uint32_t(lane) * 3u;
+    float const* p = stage_slab(Pk, gtid, slot) + uint32_t(lane) * 3u;
 #pragma unroll 8
     for (uint32_t k = 0; k < n; ++k, p += 192) {  // SMEMLayout::updateSample, megakernel.cuh:59-79
       f3 const L = mk3(p[0], p[1], p[2]);
@@ -575,40 +592,46 @@ DMT_DEV void item_fold(KArgs Pk, uint32_t gtid, int lane, uint32_t seq) {
   }
 }
 
-// wave-level bookkeeping of the two live items
-struct WaveSched {
-  uint32_t cur = 0, fetched = 0;
-  bool exhausted = false;
-};
-DMT_DEV bool sched_begin(KArgs Pk, int lane, WaveSched& W, LaneSched& Ls) {
-  if (!item_fetch(Pk, lane, 0u)) return false;
-  W.fetched = 1;
-  Ls.quota = lane_quota(0u);
+DMT_DEV bool sched_begin(KArgs Pk, int lane, WaveSched& W) {
+  uint32_t units = 0;
+  if (!item_fetch(Pk, lane, 0u, units)) return false;
+  W.fetched = 1, W.alloc = 0, W.nextUnit = 0, W.totalUnits = units;
   return true;
 }
-// a lane with nothing in flight and nothing left to start in its item moves on to the wave's next item
-// (fetched on demand, so that at the end of a launch no wave sits on an item it is not yet working on)
-DMT_DEV void sched_hop(KArgs Pk, int lane, WaveSched& W, LaneSched& Ls, bool laneIdle) {
-  bool const wantHop = laneIdle && Ls.started == Ls.quota;
-  if (!W.exhausted && W.fetched - W.cur < 2u && __any(wantHop && Ls.seq + 1u == W.fetched)) {
-    if (item_fetch(Pk, lane, W.fetched)) ++W.fetched;
-    else W.exhausted = true;
+
+// Hand the next units of the wave's items to the lanes that ask for one (`want`) and prepare them.
+DMT_DEV void sched_draw(KArgs Pk, int lane, WaveSched& W, LaneSched& Ls, bool want) {
+  if (W.nextUnit == W.totalUnits) {  // item `alloc` is used up: move to the next one, fetching it if there is room
+    if (W.alloc + 1u == W.fetched && !W.exhausted && W.fetched - W.cur < 2u) {
+      uint32_t units = 0;
+      if (item_fetch(Pk, lane, W.fetched, units)) ++W.fetched, ++W.alloc, W.nextUnit = 0, W.totalUnits = units;
+      else W.exhausted = true;
+    }
   }
-  if (wantHop && Ls.seq + 1u < W.fetched) {
-    ++Ls.seq;
-    Ls.started = 0, Ls.nDone = 0, Ls.prepared = false;
-    Ls.quota = lane_quota(Ls.seq);
-  }
+  uint32_t const avail = W.totalUnits - W.nextUnit;
+  if (avail == 0u) return;
+  unsigned long long const m = __ballot(want);
+  uint32_t const rank = uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+  uint32_t const cnt = uint32_t(__popcll(m));
+  if (want && rank < avail) prepare_unit(Pk, W.alloc, W.nextUnit + rank, Ls);
+  W.nextUnit += cnt < avail ? cnt : avail;
 }
-// item cur is complete when no lane is on it any more: fold it, fetch a new one; false = the wave is done
+
+// item cur: all units drawn and none of them still in a lane -> fold it; false = the wave has no work left
 DMT_DEV bool sched_retire(KArgs Pk, uint32_t gtid, int lane, WaveSched& W) {
   item_fold(Pk, gtid, lane, W.cur);
   ++W.cur;
-  if (W.cur == W.fetched && !W.exhausted) {
-    if (item_fetch(Pk, lane, W.fetched)) ++W.fetched;
-    else W.exhausted = true;
+  if (W.cur == W.fetched) {  // no live item
+    uint32_t units = 0;
+    if (W.exhausted || !item_fetch(Pk, lane, W.fetched, units)) return false;
+    ++W.fetched, W.alloc = W.cur, W.nextUnit = 0, W.totalUnits = units;
   }
-  return W.cur != W.fetched;
+  return true;
+}
+// does this lane still hold a sample of the item in slot `curSlot`?
+DMT_DEV bool lane_holds(PathState const& st, LaneSched const& Ls, bool curSlot) {
+  return (st.active && ((st.sidx >> 31) != 0u) == curSlot) || (Ls.prepared && Ls.prepSlot == curSlot) ||
+         (st.finPending && ((get_finIdx() >> 31) != 0u) == curSlot);
 }
 
 template <bool STATS>
@@ -633,24 +656,22 @@ DMT_DEV void megakernel_body() {
   WaveSched W;
   LaneSched Ls;
   PathState st{};
-  auto sink = [&](f3 L) { stage_sample(Pk, gtid, lane, Ls, L); };
-  if (sched_begin(Pk, lane, W, Ls)) {
+  auto sink = [&](f3 L, uint32_t sidx) { stage_sample(Pk, gtid, sidx, L); };
+  if (sched_begin(Pk, lane, W)) {
     for (;;) {
-      sched_hop(Pk, lane, W, Ls, !st.active && !st.hasShadow);
-      bool const needPrep = !Ls.prepared && Ls.started < Ls.quota;
+      bool const needPrep = !Ls.prepared;
       bool const starving = !st.active && needPrep;
-      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) {
-        if (needPrep) prepare_lane_sample(Pk, lane, Ls);
-      }
+      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) sched_draw(Pk, lane, W, Ls, needPrep);
       if (!st.active && Ls.prepared) {
         path_begin_prepared(st);
-        ++Ls.started, Ls.prepared = false;
+        Ls.prepared = false;
         if constexpr (STATS) ++ls.samples;
       }
-      bool const busyCur = Ls.seq == W.cur && (st.active || st.hasShadow || Ls.started < Ls.quota);
-      if (!__any(busyCur)) {
-        if (!sched_retire(Pk, gtid, lane, W)) break;
-        continue;
+      if (W.alloc != W.cur || W.nextUnit == W.totalUnits) {  // item cur has no units left: is it complete?
+        if (!__any(lane_holds(st, Ls, (W.cur & 1u) != 0u))) {
+          if (!sched_retire(Pk, gtid, lane, W)) break;
+          continue;
+        }
       }
       lane_step<BVH, STATS>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
     }
@@ -676,7 +697,7 @@ DMT_DEV void megakernel_body_bvh() {
   WaveSched W;
   LaneSched Ls;
   PathState st{};
-  auto sink = [&](f3 L) { stage_sample(Pk, gtid, lane, Ls, L); };
+  auto sink = [&](f3 L, uint32_t sidx) { stage_sample(Pk, gtid, sidx, L); };
   Traversal tv{};
   tv.phase = TR_IDLE;
   {
@@ -684,19 +705,16 @@ DMT_DEV void megakernel_body_bvh() {
     tv.stack.ovf = bvh0.overflow + gtid;
     tv.stack.stride = bvh0.overflowStride;
   }
-  if (sched_begin(Pk, lane, W, Ls)) {
+  if (sched_begin(Pk, lane, W)) {
     for (;;) {
-      // A. item hop, sample preparation / start (only lanes between rounds)
+      // A. draw + prepare units, start samples (only lanes between rounds start one)
       bool const idle = tv.phase == TR_IDLE;
-      sched_hop(Pk, lane, W, Ls, idle && !st.active && !st.hasShadow);
-      bool const needPrep = !Ls.prepared && Ls.started < Ls.quota;
+      bool const needPrep = !Ls.prepared;
       bool const starving = idle && !st.active && needPrep;
-      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) {
-        if (needPrep) prepare_lane_sample(Pk, lane, Ls);
-      }
+      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) sched_draw(Pk, lane, W, Ls, needPrep);
       if (idle && !st.active && Ls.prepared) {
         path_begin_prepared(st);
-        ++Ls.started, Ls.prepared = false;
+        Ls.prepared = false;
         if constexpr (STATS) ++ls.samples;
       }
       // B. start a round: closest-hit ray and/or pending shadow ray
@@ -713,11 +731,12 @@ DMT_DEV void megakernel_body_bvh() {
         }
         if constexpr (STATS) ls.closest += tv.doC ? 1u : 0u, ls.shadow += tv.doS ? 1u : 0u;
       }
-      // R. the older live item is complete when no lane is on it any more
-      bool const busyCur = Ls.seq == W.cur && (tv.phase != TR_IDLE || Ls.started < Ls.quota);
-      if (!__any(busyCur)) {
-        if (!sched_retire(Pk, gtid, lane, W)) break;
-        continue;
+      // R. item cur has no units left: is it complete?
+      if (W.alloc != W.cur || W.nextUnit == W.totalUnits) {
+        if (!__any(lane_holds(st, Ls, (W.cur & 1u) != 0u))) {
+          if (!sched_retire(Pk, gtid, lane, W)) break;
+          continue;
+        }
       }
       // C. traversal ("while-while"): run node steps until no traversing lane sits on an inner node, then
       //    one leaf step for every lane sitting on a leaf; repeat until enough lanes wait for shading
@@ -771,7 +790,7 @@ __global__ void k_test_trace(RenderParams P, bool useBvh, int n, int32_t const* 
     ColdArgs const c = load_cold_args(k);
     path_begin(st, c.cam, c.sp, pxs[i], pys[i], halton_pixel_base(c.sp, pxs[i], pys[i]), uint32_t(ss[i]));
   }
-  auto store = [&](f3 L) { L3[3 * i] = L.x, L3[3 * i + 1] = L.y, L3[3 * i + 2] = L.z; };
+  auto store = [&](f3 L, uint32_t) { L3[3 * i] = L.x, L3[3 * i + 1] = L.y, L3[3 * i + 2] = L.z; };
   uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
   for (;;) {
     if (!__any(st.active || st.hasShadow)) break;
