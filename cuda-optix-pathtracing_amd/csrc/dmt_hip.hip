@@ -1006,7 +1006,7 @@ struct dmt_ctx {
   float* d_stage = nullptr;        // staging of finished samples, [wave][chunkSpp][64] float3
   size_t stageFloats = 0;
   size_t tileDoneCap = 0;
-  uint32_t chunkSpp = 128;         // samples per work item
+  uint32_t chunkSpp = 16;          // samples per work item
   int maxDepth = 32;
   int accel = DMT_ACCEL_BRUTE_FORCE;
   int rank = 0, world = 1;

@@ -492,13 +492,13 @@ def test_sample_chunking_is_bit_exact(renderer, O):
     are a scheduling knob only: any chunk size gives the same film bits as one item per tile."""
     _load_cornell(renderer, O, 200, 136, 8)
     films = []
-    for chunk in (0, 1, 7, 64, 1000):
+    for chunk in (0, 1, 7, 16, 64, 1000):
         renderer.set_chunk(chunk)
         renderer.film_clear()
         renderer.render(96)
         renderer.sync()
         films.append(renderer.download_film())
-    renderer.set_chunk(128)
+    renderer.set_chunk(16)
     for f in films[1:]:
         assert np.array_equal(films[0][0], f[0]) and np.array_equal(films[0][1], f[1])
     assert np.all(films[0][1][..., 3] == 96)
