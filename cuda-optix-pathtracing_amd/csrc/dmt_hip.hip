@@ -20,6 +20,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -44,7 +45,8 @@ struct RenderParams {
   int width, height;
   int x0, y0, x1, y1;     // pixel region
   int tx0, ty0, rtx;      // tile grid of the region: origin (in tiles) and tiles per row
-  uint32_t numItems;      // owned tiles
+  uint32_t numItems;      // owned tiles << subShift
+  uint32_t subShift;      // an owned 8x8 tile is scheduled as 1 << subShift row bands (1, 2 or 4)
   int rank, world;
   uint32_t sampleOffset, spp;
   uint32_t chunkSpp;       // samples per work item
@@ -411,7 +413,7 @@ struct TileArgs {  // what a wave needs when it picks up a new work item
   float4* m2;
   uint32_t* counter;
   int width, x0, y0, x1, y1, tx0, ty0, rtx;
-  uint32_t numItems, sampleOffset, spp, chunkSpp, numChunks;
+  uint32_t numItems, subShift, sampleOffset, spp, chunkSpp, numChunks;
   uint32_t* tileDone;
   uint32_t* errorFlag;
   float* stage;
@@ -422,7 +424,7 @@ DMT_DEV TileArgs load_tile_args(KArgs k) {
   TileArgs t;
   t.mean = k->mean, t.m2 = k->m2, t.counter = k->counter, t.width = k->width;
   t.x0 = k->x0, t.y0 = k->y0, t.x1 = k->x1, t.y1 = k->y1, t.tx0 = k->tx0, t.ty0 = k->ty0, t.rtx = k->rtx;
-  t.numItems = k->numItems, t.sampleOffset = k->sampleOffset, t.spp = k->spp, t.rank = k->rank, t.world = k->world;
+  t.numItems = k->numItems, t.subShift = k->subShift, t.sampleOffset = k->sampleOffset, t.spp = k->spp, t.rank = k->rank, t.world = k->world;
   t.chunkSpp = k->chunkSpp, t.numChunks = k->numChunks, t.tileDone = k->tileDone, t.errorFlag = k->errorFlag, t.stage = k->stage;
   return t;
 }
@@ -482,11 +484,15 @@ DMT_DEV bool item_fetch(KArgs Pk, int lane, uint32_t seq, uint32_t& units) {
   if (work >= T.numItems * T.numChunks) return false;
   uint32_t const chunk = work / T.numItems;
   uint32_t const item = work - chunk * T.numItems;
-  uint32_t const j = uint32_t(T.rank) + item * uint32_t(T.world);
+  // an owned tile is scheduled as 1 << subShift bands of 8 >> subShift rows: more, smaller items when this GPU
+  // has fewer tiles than resident waves (lanes beyond the band are simply "outside")
+  uint32_t const band = item & ((1u << T.subShift) - 1u);
+  uint32_t const rows = 8u >> T.subShift;
+  uint32_t const j = uint32_t(T.rank) + (item >> T.subShift) * uint32_t(T.world);
   int const px0 = (T.tx0 + int(j % uint32_t(T.rtx))) * 8;
-  int const py0 = (T.ty0 + int(j / uint32_t(T.rtx))) * 8;
+  int const py0 = (T.ty0 + int(j / uint32_t(T.rtx))) * 8 + int(band * rows);
   int const px = px0 + (lane & 7), py = py0 + (lane >> 3);
-  bool const inside = px >= T.x0 && px < T.x1 && py >= T.y0 && py < T.y1;
+  bool const inside = uint32_t(lane >> 3) < rows && px >= T.x0 && px < T.x1 && py >= T.y0 && py < T.y1;
   uint32_t const s0 = T.sampleOffset + chunk * T.chunkSpp;
   uint32_t const s1 = s0 + T.chunkSpp < T.sampleOffset + T.spp ? s0 + T.chunkSpp : T.sampleOffset + T.spp;
   uint32_t const slot = seq & 1u;
@@ -592,6 +598,18 @@ DMT_DEV void item_fold(KArgs Pk, uint32_t gtid, int lane, uint32_t seq) {
   }
 }
 
+// has the tile's previous chunk been folded, i.e. may item `seq` be folded without waiting?
+DMT_DEV bool fold_ready(KArgs Pk, int lane, uint32_t seq) {
+  uint32_t const* const d = s_desc[threadIdx.x >> 6][seq & 1u];
+  uint32_t const chunk = uint32_t(__builtin_amdgcn_readfirstlane(int(d[0])));
+  if (chunk == 0u) return true;
+  uint32_t const item = uint32_t(__builtin_amdgcn_readfirstlane(int(d[1])));
+  uint32_t done = 0;
+  if (lane == 0) done = __hip_atomic_load(&kargs(Pk)->tileDone[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  done = uint32_t(__builtin_amdgcn_readfirstlane(int(done)));
+  return done >= chunk;
+}
+
 DMT_DEV bool sched_begin(KArgs Pk, int lane, WaveSched& W) {
   uint32_t units = 0;
   if (!item_fetch(Pk, lane, 0u, units)) return false;
@@ -669,8 +687,13 @@ DMT_DEV void megakernel_body() {
       }
       if (W.alloc != W.cur || W.nextUnit == W.totalUnits) {  // item cur has no units left: is it complete?
         if (!__any(lane_holds(st, Ls, (W.cur & 1u) != 0u))) {
-          if (!sched_retire(Pk, gtid, lane, W)) break;
-          continue;
+          // fold it now if the tile's previous chunk is in the film; otherwise keep tracing the other item
+          // meanwhile (matters when a GPU has fewer tiles than resident waves: 1/8 of a 1024^2 frame)
+          bool const busy = __any(st.active || st.hasShadow);
+          if (!busy || fold_ready(Pk, lane, W.cur)) {
+            if (!sched_retire(Pk, gtid, lane, W)) break;
+            continue;
+          }
         }
       }
       lane_step<BVH, STATS>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
@@ -734,8 +757,11 @@ DMT_DEV void megakernel_body_bvh() {
       // R. item cur has no units left: is it complete?
       if (W.alloc != W.cur || W.nextUnit == W.totalUnits) {
         if (!__any(lane_holds(st, Ls, (W.cur & 1u) != 0u))) {
-          if (!sched_retire(Pk, gtid, lane, W)) break;
-          continue;
+          bool const busy = __any(tv.phase != TR_IDLE);
+          if (!busy || fold_ready(Pk, lane, W.cur)) {  // see megakernel_body
+            if (!sched_retire(Pk, gtid, lane, W)) break;
+            continue;
+          }
         }
       }
       // C. traversal ("while-while"): run node steps until no traversing lane sits on an inner node, then
@@ -1006,7 +1032,8 @@ struct dmt_ctx {
   float* d_stage = nullptr;        // staging of finished samples, [wave][chunkSpp][64] float3
   size_t stageFloats = 0;
   size_t tileDoneCap = 0;
-  uint32_t chunkSpp = 16;          // samples per work item
+  uint32_t chunkSpp = 0;           // samples per work item, 0 = automatic
+  int subShift = -1;               // row bands per tile (log2); -1 = choose per launch
   int maxDepth = 32;
   int accel = DMT_ACCEL_BRUTE_FORCE;
   int rank = 0, world = 1;
@@ -1238,6 +1265,10 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
   ctx->cuCount = prop.multiProcessorCount;
   ctx->blocksPerCU = bpc > 0 ? bpc : 1;
   ctx->blocksPerCUBvh = bpcBvh > 0 ? bpcBvh : 1;
+  if (char const* e2 = std::getenv("DMT_SUB_SHIFT")) {  // scheduling experiments only: results do not depend on it
+    int const v = std::atoi(e2);
+    ctx->subShift = v < 0 ? -1 : (v > 2 ? 2 : v);
+  }
   *out = ctx;
   return DMT_OK;
 }
@@ -1490,8 +1521,16 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   P.sampleOffset = sample_offset, P.spp = spp;
   P.maxDepth = ctx->maxDepth;
   if (P.numItems == 0) return DMT_OK;
-  // samples per work item; bounded so the staging area (768 B per sample index per resident wave) stays small
-  P.chunkSpp = ctx->chunkSpp ? ctx->chunkSpp : spp;
+  {  // fewer owned tiles than ~4 per resident wave: schedule row bands of the tiles instead of whole tiles
+    uint32_t const waves = uint32_t(ctx->cuCount) * uint32_t(ctx->accel == DMT_ACCEL_BVH ? ctx->blocksPerCUBvh : ctx->blocksPerCU) * 4u;
+    P.subShift = ctx->subShift >= 0 ? uint32_t(ctx->subShift) : 0u;
+    if (ctx->subShift < 0)
+      while (P.subShift < 2u && (uint64_t(P.numItems) << P.subShift) < 4ull * waves) ++P.subShift;
+    P.numItems <<= P.subShift;
+  }
+  // samples per work item: automatic = 16 per 64 pixels (1 024 path samples per item); bounded so the staging
+  // area (768 B per sample index per resident wave and slot) stays small
+  P.chunkSpp = ctx->chunkSpp ? ctx->chunkSpp : (16u << P.subShift);
   if (P.chunkSpp > spp) P.chunkSpp = spp;
   if (P.chunkSpp > kMaxChunkSpp) P.chunkSpp = kMaxChunkSpp;
   P.numChunks = (spp + P.chunkSpp - 1) / P.chunkSpp;

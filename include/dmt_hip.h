@@ -93,7 +93,7 @@ int dmt_set_accel(dmt_ctx* ctx, int mode);
 /* tile partition for multi-GPU rendering: this context renders only the 8x8-pixel tiles whose
  * index (row-major over the tile grid) is congruent to `rank` modulo `world`.  Default 0 of 1. */
 int dmt_set_partition(dmt_ctx* ctx, int rank, int world);
-/* samples per work item inside one dmt_render pass (default 16; 0 = as many as the staging area allows, 512).  Purely a
+/* samples per work item inside one dmt_render pass (0 = automatic, the default: 1 024 path samples per item; at most 512).  Purely a
  * scheduling knob: a pixel's samples are folded in index order for any value, the film is bit-identical. */
 int dmt_set_chunk(dmt_ctx* ctx, uint32_t samples_per_item);
 /* borrow an external hipStream_t (e.g. the caller's); NULL restores the context's own stream */

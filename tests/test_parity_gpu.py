@@ -487,6 +487,25 @@ def test_bvh_million_triangles(renderer, pkg, O):
     renderer.set_accel(0)
 
 
+def test_row_band_scheduling_is_bit_exact(pkg, O, monkeypatch):
+    """A GPU that owns fewer tiles than it has resident waves schedules row bands of its tiles (2 or 4 items per
+    8x8 tile).  Scheduling only: the film must not change by a bit, partial tiles and partitions included."""
+    scene = O.cornell_box(200, 136)
+    films = []
+    for shift in ("0", "1", "2"):
+        monkeypatch.setenv("DMT_SUB_SHIFT", shift)
+        with pkg.Renderer(0) as r:
+            r.upload_scene(scene)
+            r.set_limits(8)
+            r.set_partition(1, 3)
+            r.render(40, region=(3, 5, 197, 131))
+            r.sync()
+            films.append(r.download_film())
+    for f in films[1:]:
+        assert np.array_equal(films[0][0], f[0]) and np.array_equal(films[0][1], f[1])
+    assert films[0][1][..., 3].max() == 40
+
+
 def test_sample_chunking_is_bit_exact(renderer, O):
     """In-launch sample chunks (work items = tile x chunk, ordered per tile by release/acquire counters)
     are a scheduling knob only: any chunk size gives the same film bits as one item per tile."""
@@ -498,7 +517,7 @@ def test_sample_chunking_is_bit_exact(renderer, O):
         renderer.render(96)
         renderer.sync()
         films.append(renderer.download_film())
-    renderer.set_chunk(16)
+    renderer.set_chunk(0)
     for f in films[1:]:
         assert np.array_equal(films[0][0], f[0]) and np.array_equal(films[0][1], f[1])
     assert np.all(films[0][1][..., 3] == 96)
