@@ -244,8 +244,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "k_megakernel_bvh" if use_bvh else "k_megakernel", "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
                 "algorithmic_bytes_per_sample": round(b_sample, 1),
-                "note": ("1 M triangles (48 MB) + BVH nodes exceed L2; per-lane incoherent node/triangle gathers: "
-                         "memory-latency bound" if use_bvh else
+                "note": ("1 M triangles + BVH nodes (110 MB) exceed the 32 MB of L2 but sit in the 256 MiB Infinity Cache: "
+                         "the per-lane incoherent node/triangle gathers are served from there, so achieved algorithmic "
+                         "GB/s can approach or exceed the HBM peak; the kernel is divergence/latency bound" if use_bvh else
                          "26-triangle scene is cache/SGPR resident: algorithmic bytes are served by the scalar cache, "
                          "the kernel is VALU/latency bound (SURVEY 8d); see valu_view"),
                 "per_sample": {k: round(v / stats["samples"], 3) for k, v in stats.items() if k != "samples"},

@@ -51,7 +51,7 @@ def load_library():
 # every symbol include/dmt_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTED_SYMBOLS = [
     "dmt_ctx_create", "dmt_ctx_destroy", "dmt_last_error", "dmt_upload_triangles", "dmt_upload_bsdfs",
-    "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_partition", "dmt_set_chunk",
+    "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_partition", "dmt_set_chunk", "dmt_render_profile",
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
     "dmt_render", "dmt_render_stats", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
     "dmt_test_sampler", "dmt_test_camera_rays", "dmt_test_bsdf", "dmt_test_light", "dmt_test_half",
@@ -195,6 +195,15 @@ class Renderer:
         self._check(self._lib.dmt_render_stats(self._ctx, C.c_uint32(sample_offset), C.c_uint32(spp), int(x0), int(y0),
                                                int(x1), int(y1), _p(out)), "dmt_render_stats")
         keys = ["samples", "closest_rays", "shadow_rays", "node_visits", "tri_tests", "bounces"]
+        return dict(zip(keys, (int(v) for v in out)))
+
+    def render_profile(self, spp, sample_offset=0, region=None):
+        x0, y0, x1, y1 = region if region is not None else (0, 0, self.width, self.height)
+        out = np.zeros(16, np.uint64)
+        self._check(self._lib.dmt_render_profile(self._ctx, C.c_uint32(sample_offset), C.c_uint32(spp), int(x0), int(y0),
+                                                 int(x1), int(y1), _p(out)), "dmt_render_profile")
+        keys = ["samples", "closest_rays", "shadow_rays", "node_visits", "tri_tests", "bounces", "it_node", "it_leaf",
+                "it_shade", "it_outer", "it_prep", "lanes_leaf", "lanes_shade", "lanes_prep"]
         return dict(zip(keys, (int(v) for v in out)))
 
     def sync(self):

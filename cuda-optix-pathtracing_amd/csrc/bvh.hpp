@@ -31,8 +31,20 @@ constexpr int kBvhMaxDepth = 48;   // depth bound (binary levels, hence also 4-w
 constexpr int kBvhLdsStack = 16;   // traversal stack entries kept in LDS per lane
 constexpr int kBvhOverflowStack = 3 * kBvhMaxDepth - kBvhLdsStack;  // the rest, per lane, in global memory
 
-// child reference: kBvhEmpty | inner node index | kBvhLeafFlag | (count-1) << 28 | first triangle slot
+// child reference: kBvhEmpty | inner node index | kBvhLeafFlag | (count-1) << 28 | first
+// (builder: count triangles from slot `first`; device: count triangle PAIRS from pair `first`)
 inline uint32_t bvhLeafRef(uint32_t first, uint32_t count) { return kBvhLeafFlag | ((count - 1u) << 28) | first; }
+
+// Leaf storage on the device: two triangles interleaved component by component, so that the 16-byte loads
+// deliver (first, second) register pairs ready for packed math; one 128-byte cache line per pair.  A leaf of
+// 1-4 triangles is 1-2 consecutive pairs; an odd leaf repeats its last triangle (same original index, so the
+// repeated test can never win the tie-break against itself).
+struct TriPair {  // 128 B
+  float p0x[2], p0y[2], p0z[2], e0x[2], e0y[2], e0z[2], e1x[2], e1y[2], e1z[2];
+  uint32_t orig[2];  // ORIGINAL triangle indices (brute-force tie-break, shading)
+  uint32_t pad[12];
+};
+static_assert(sizeof(TriPair) == 128, "pair size");
 
 struct Bvh4Node {  // 128 B
   float minx[4], miny[4], minz[4];

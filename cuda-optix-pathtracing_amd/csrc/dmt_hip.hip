@@ -87,7 +87,7 @@ DMT_DEV SceneView load_scene(KArgs k) {
 DMT_DEV BvhView load_bvh(KArgs k) {
   k = kargs(k);
   BvhView b;
-  b.nodes = k->bvh.nodes, b.tris = k->bvh.tris, b.overflow = k->bvh.overflow, b.overflowStride = k->bvh.overflowStride;
+  b.nodes = k->bvh.nodes, b.pairs = k->bvh.pairs, b.overflow = k->bvh.overflow, b.overflowStride = k->bvh.overflowStride;
   return b;
 }
 
@@ -281,6 +281,9 @@ DMT_DEV void trace_pair_brute(KArgs k, PathState const& st, bool doC, bool doS, 
 struct LaneStats {  // stats build only
   uint32_t samples = 0, closest = 0, shadow = 0, bounces = 0;
   TraversalCounters tc;
+  // loop profile of the BVH kernel: wave-level iterations (counted by every lane, /64 on the host) and the lanes
+  // that did useful work in them
+  uint32_t itNode = 0, itLeaf = 0, itShade = 0, itOuter = 0, itPrep = 0, lanesLeaf = 0, lanesShade = 0, lanesPrep = 0;
 };
 template <bool STATS = false>
 DMT_DEV void trace_pair_bvh(KArgs k, PathState const& st, bool doC, bool doS, uint32_t gtid, int& bestTri,
@@ -662,6 +665,14 @@ DMT_DEV void flush_stats(KArgs Pk, LaneStats const& ls) {
     atomicAdd(&stats[3], (unsigned long long)ls.tc.nodes);
     atomicAdd(&stats[4], (unsigned long long)ls.tc.tris);
     atomicAdd(&stats[5], (unsigned long long)ls.bounces);
+    atomicAdd(&stats[6], (unsigned long long)ls.itNode);
+    atomicAdd(&stats[7], (unsigned long long)ls.itLeaf);
+    atomicAdd(&stats[8], (unsigned long long)ls.itShade);
+    atomicAdd(&stats[9], (unsigned long long)ls.itOuter);
+    atomicAdd(&stats[10], (unsigned long long)ls.itPrep);
+    atomicAdd(&stats[11], (unsigned long long)ls.lanesLeaf);
+    atomicAdd(&stats[12], (unsigned long long)ls.lanesShade);
+    atomicAdd(&stats[13], (unsigned long long)ls.lanesPrep);
   }
 }
 
@@ -734,7 +745,11 @@ DMT_DEV void megakernel_body_bvh() {
       bool const idle = tv.phase == TR_IDLE;
       bool const needPrep = !Ls.prepared;
       bool const starving = idle && !st.active && needPrep;
-      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) sched_draw(Pk, lane, W, Ls, needPrep);
+      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) {
+        if constexpr (STATS) ++ls.itPrep, ls.lanesPrep += needPrep ? 1u : 0u;
+        sched_draw(Pk, lane, W, Ls, needPrep);
+      }
+      if constexpr (STATS) ++ls.itOuter;
       if (idle && !st.active && Ls.prepared) {
         path_begin_prepared(st);
         Ls.prepared = false;
@@ -764,28 +779,38 @@ DMT_DEV void megakernel_body_bvh() {
           }
         }
       }
-      // C. traversal ("while-while"): run node steps until no traversing lane sits on an inner node, then
-      //    one leaf step for every lane sitting on a leaf; repeat until enough lanes wait for shading
+      // C. traversal.  Lanes sit on an inner node, on a leaf, or have finished their ray.  Each iteration runs ONE
+      //    kind of step -- node or leaf, whichever more lanes are waiting for -- so a step always serves at least
+      //    half of the traversing lanes (a plain while-while loop kept running node steps for the last few lanes
+      //    that were still descending: 11 % lane utilisation in node steps).  The loop ends when enough lanes
+      //    wait for shading.
       BvhView const bvh = load_bvh(Pk);
       for (;;) {
         bool traversing = tv.phase == TR_CLOSEST || tv.phase == TR_SHADOW;
-        if (!__any(traversing)) break;
-        if (__popcll(__ballot(tv.phase == TR_DONE)) >= DMT_BVH_SHADE_THRESHOLD) break;
-        // inner nodes (kBvhEmpty has the leaf bit set, so finished lanes drop out by themselves)
-        while (__any(traversing && !(tv.cur & kBvhLeafFlag))) {
-          if (traversing && !(tv.cur & kBvhLeafFlag)) trav_node<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
-        }
-        if (traversing && tv.cur != kBvhEmpty) trav_leaf<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
-        if (traversing && tv.cur == kBvhEmpty) {
+        if (traversing && tv.cur == kBvhEmpty) {  // ray finished: next ray of the round, or done
           if (tv.phase == TR_CLOSEST && tv.doS) {
             tv.phase = TR_SHADOW;
             trav_set_ray(tv, mk3(st.rp.ox.y, st.rp.oy.y, st.rp.oz.y), mk3(st.rp.dx.y, st.rp.dy.y, st.rp.dz.y));
           } else {
             tv.phase = TR_DONE;
+            traversing = false;
           }
+        }
+        bool const onNode = traversing && !(tv.cur & kBvhLeafFlag);
+        bool const onLeaf = traversing && (tv.cur & kBvhLeafFlag) != 0u;  // cur != kBvhEmpty here
+        int const nNode = __popcll(__ballot(onNode)), nLeaf = __popcll(__ballot(onLeaf));
+        if (nNode + nLeaf == 0) break;
+        if (__popcll(__ballot(tv.phase == TR_DONE)) >= DMT_BVH_SHADE_THRESHOLD) break;
+        if (nNode >= nLeaf) {
+          if constexpr (STATS) ++ls.itNode;
+          if (onNode) trav_node<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
+        } else {
+          if constexpr (STATS) ++ls.itLeaf, ls.lanesLeaf += onLeaf ? 1u : 0u;
+          if (onLeaf) trav_leaf<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
         }
       }
       // D. resolve + shade every lane that has finished its round
+      if constexpr (STATS) ++ls.itShade, ls.lanesShade += tv.phase == TR_DONE ? 1u : 0u;
       if (tv.phase == TR_DONE) {
         if constexpr (STATS) ls.bounces += (tv.doC && tv.bestTri >= 0 && st.depth < kargs(Pk)->maxDepth) ? 1u : 0u;
         lane_finish(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
@@ -1010,7 +1035,7 @@ struct dmt_ctx {
   std::vector<float> h_xs, h_ys, h_zs;  // host copy of the soup (the builder's input)
   std::vector<uint32_t> h_mat;
   Bvh4Node* d_bvhNodes = nullptr;
-  TriIsect* d_trisBvh = nullptr;
+  TriPair* d_trisBvh = nullptr;   // leaf storage of the BVH
   uint32_t* d_overflow = nullptr;
   size_t overflowThreads = 0;
   bool haveBvh = false;
@@ -1134,7 +1159,7 @@ SceneView sceneView(dmt_ctx const* c) {
 
 BvhView bvhView(dmt_ctx const* c, size_t threads) {
   BvhView b;
-  b.nodes = c->d_bvhNodes, b.tris = c->d_trisBvh, b.overflow = c->d_overflow;
+  b.nodes = c->d_bvhNodes, b.pairs = c->d_trisBvh, b.overflow = c->d_overflow;
   b.overflowStride = uint32_t(threads);
   return b;
 }
@@ -1173,25 +1198,44 @@ int ensureOverflow(dmt_ctx* ctx, size_t threads) {
 // (re)build the 4-wide BVH of the uploaded soup and upload nodes + slot-ordered triangle records
 int buildBvh(dmt_ctx* ctx) {
   uint32_t const n = ctx->triCount;
-  bvh_build::Result const r = bvh_build::build(ctx->h_xs.data(), ctx->h_ys.data(), ctx->h_zs.data(), n);
-  std::vector<TriIsect> slots(n);
-  for (uint32_t s = 0; s < n; ++s) {
-    uint32_t const i = r.slotToTri[s];
+  bvh_build::Result r = bvh_build::build(ctx->h_xs.data(), ctx->h_ys.data(), ctx->h_zs.data(), n);
+  // leaf storage: triangle pairs (bvh.hpp TriPair); leaf references are rewritten from (first slot, triangles)
+  // to (first pair, pairs).  Edges are the reference's own subtractions (CC/private/shapes.cu:10-11) in IEEE fp32.
+  std::vector<TriPair> pairs;
+  pairs.reserve(size_t(n) / 2 + r.nodes.size());
+  auto put = [&](TriPair& P, int half, uint32_t slot) {
+    uint32_t const i = r.slotToTri[slot];
     float const* xs = &ctx->h_xs[4 * size_t(i)];
     float const* ys = &ctx->h_ys[4 * size_t(i)];
     float const* zs = &ctx->h_zs[4 * size_t(i)];
-    TriIsect& t = slots[s];
-    t.p0x = xs[0], t.p0y = ys[0], t.p0z = zs[0];
-    t.e0x = xs[1] - xs[0], t.e0y = ys[1] - ys[0], t.e0z = zs[1] - zs[0];
-    t.e1x = xs[2] - xs[0], t.e1y = ys[2] - ys[0], t.e1z = zs[2] - zs[0];
-    t.matId = ctx->h_mat[i], t.pad0 = i, t.pad1 = 0;
+    P.p0x[half] = xs[0], P.p0y[half] = ys[0], P.p0z[half] = zs[0];
+    P.e0x[half] = xs[1] - xs[0], P.e0y[half] = ys[1] - ys[0], P.e0z[half] = zs[1] - zs[0];
+    P.e1x[half] = xs[2] - xs[0], P.e1y[half] = ys[2] - ys[0], P.e1z[half] = zs[2] - zs[0];
+    P.orig[half] = i;
+  };
+  for (Bvh4Node& nd : r.nodes) {
+    for (int k = 0; k < 4; ++k) {
+      uint32_t const ref = nd.child[k];
+      if (ref == kBvhEmpty || !(ref & kBvhLeafFlag)) continue;
+      uint32_t const first = ref & 0x0FFFFFFFu, cnt = ((ref >> 28) & 7u) + 1u;
+      uint32_t const firstPair = uint32_t(pairs.size());
+      for (uint32_t j = 0; j < cnt; j += 2) {
+        TriPair P{};
+        put(P, 0, first + j);
+        put(P, 1, first + (j + 1 < cnt ? j + 1 : j));
+        pairs.push_back(P);
+      }
+      if (pairs.size() > 0x0FFFFFFFull) return fail(ctx, DMT_ERR_INVALID, "BVH: too many triangle pairs");
+      nd.child[k] = bvhLeafRef(firstPair, uint32_t(pairs.size()) - firstPair);
+    }
   }
   int rc = devAlloc(ctx, &ctx->d_bvhNodes, r.nodes.size());
   if (rc) return rc;
-  rc = devAlloc(ctx, &ctx->d_trisBvh, size_t(n));
+  rc = devAlloc(ctx, &ctx->d_trisBvh, pairs.size());
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpy(ctx->d_bvhNodes, r.nodes.data(), r.nodes.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice));
-  if (n) HIP_TRY(ctx, hipMemcpy(ctx->d_trisBvh, slots.data(), size_t(n) * sizeof(TriIsect), hipMemcpyHostToDevice));
+  if (!pairs.empty())
+    HIP_TRY(ctx, hipMemcpy(ctx->d_trisBvh, pairs.data(), pairs.size() * sizeof(TriPair), hipMemcpyHostToDevice));
   ctx->bvhDepth = r.depth;
   ctx->bvhNodeCount = uint32_t(r.nodes.size());
   ctx->haveBvh = true;
@@ -1486,9 +1530,9 @@ int dmt_download_film(dmt_ctx* ctx, float* mean4, float* m24) {
   return DMT_OK;
 }
 
-static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1, uint64_t* stats6) {
+static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1, uint64_t* stats6, int nstats) {
   if (!ctx) return DMT_ERR_INVALID;
-  if (stats6) memset(stats6, 0, 6 * sizeof(uint64_t));
+  if (stats6) memset(stats6, 0, size_t(nstats) * sizeof(uint64_t));
   if (!(ctx->haveTris && ctx->haveBsdfs && ctx->haveLights && ctx->haveCamera))
     return fail(ctx, DMT_ERR_STATE, "dmt_render: upload triangles, bsdfs, lights and set the camera first");
   // the Halton index sample * stride must stay inside int32 (CC/private/rng.cu:229)
@@ -1579,13 +1623,13 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
     P.bvh = bvhView(ctx, size_t(blocks) * 256);
     if (stats6) {
       unsigned long long* dstats = nullptr;
-      HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dstats), 6 * sizeof(unsigned long long)));
-      HIP_TRY(ctx, hipMemsetAsync(dstats, 0, 6 * sizeof(unsigned long long), ctx->stream));
+      HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dstats), 16 * sizeof(unsigned long long)));
+      HIP_TRY(ctx, hipMemsetAsync(dstats, 0, 16 * sizeof(unsigned long long), ctx->stream));
       P.stats = dstats;
       hipLaunchKernelGGL(k_megakernel_bvh_stats, dim3(blocks), dim3(256), 0, ctx->stream, P);
       hipError_t e = hipGetLastError();
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      if (e == hipSuccess) e = hipMemcpy(stats6, dstats, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(stats6, dstats, size_t(nstats) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
       (void)hipFree(dstats);
       HIP_TRY(ctx, e);
       return DMT_OK;
@@ -1650,17 +1694,24 @@ int dmt_bvh_validate(const float* xs, const float* ys, const float* zs, size_t c
   return ok && maxLeaf <= kBvhMaxLeafTris ? DMT_OK : DMT_ERR_STATE;
 }
 
-static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1, uint64_t* stats6);
+static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1, uint64_t* stats6, int nstats);
 
 int dmt_render(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1) {
-  return renderImpl(ctx, sample_offset, spp, x0, y0, x1, y1, nullptr);
+  return renderImpl(ctx, sample_offset, spp, x0, y0, x1, y1, nullptr, 0);
 }
 
 int dmt_render_stats(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1,
                      uint64_t* stats6) {
   if (!ctx || !stats6) return DMT_ERR_INVALID;
   if (ctx->accel != DMT_ACCEL_BVH) return fail(ctx, DMT_ERR_STATE, "dmt_render_stats: only the BVH path has device counters");
-  return renderImpl(ctx, sample_offset, spp, x0, y0, x1, y1, stats6);
+  return renderImpl(ctx, sample_offset, spp, x0, y0, x1, y1, stats6, 6);
+}
+
+int dmt_render_profile(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1,
+                       uint64_t* stats16) {
+  if (!ctx || !stats16) return DMT_ERR_INVALID;
+  if (ctx->accel != DMT_ACCEL_BVH) return fail(ctx, DMT_ERR_STATE, "dmt_render_profile: only the BVH path has device counters");
+  return renderImpl(ctx, sample_offset, spp, x0, y0, x1, y1, stats16, 16);
 }
 
 int dmt_sync(dmt_ctx* ctx) {

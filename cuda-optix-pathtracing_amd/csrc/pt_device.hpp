@@ -401,6 +401,7 @@ struct MTPair {
 DMT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DMT_DEV v2f fma_(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 DMT_DEV v2f fma_(v2f a, float b, v2f c) { return __builtin_elementwise_fma(a, v2f{b, b}, c); }
+DMT_DEV v2f fma_(float a, v2f b, v2f c) { return __builtin_elementwise_fma(v2f{a, a}, b, c); }
 DMT_DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 DMT_DEV v2f rcp_(v2f x) { return v2f{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
 // (the triangle is passed as nine scalars on purpose: handed over as a struct, LLVM keeps part of it in
@@ -417,6 +418,23 @@ DMT_DEV void mt_core9(float p0x, float p0y, float p0z, float e0x, float e0y, flo
   T const qx = fma_(ovy, e0z, -(ovz * e0y));
   T const qy = fma_(ovz, e0x, -(ovx * e0z));
   T const qz = fma_(ovx, e0y, -(ovy * e0x));
+  u = inv * fma_(cz, ovz, fma_(cy, ovy, cx * ovx));
+  v = inv * fma_(qz, dz, fma_(qy, dy, qx * dx));
+  tt = inv * fma_(qz, e1z, fma_(qy, e1y, qx * e1x));
+}
+// One ray against TWO triangles held as packed pairs (.x / .y = first / second triangle): the same operations
+// in the same order as mt_core9, element by element, so each half is bit-identical to the scalar test.
+DMT_DEV void mt_core9_tri2(v2f p0x, v2f p0y, v2f p0z, v2f e0x, v2f e0y, v2f e0z, v2f e1x, v2f e1y, v2f e1z, float ox,
+                           float oy, float oz, float dx, float dy, float dz, v2f& det, v2f& tt, v2f& u, v2f& v) {
+  v2f const cx = fma_(dy, e1z, -(dz * e1y));
+  v2f const cy = fma_(dz, e1x, -(dx * e1z));
+  v2f const cz = fma_(dx, e1y, -(dy * e1x));
+  det = fma_(cz, e0z, fma_(cy, e0y, cx * e0x));
+  v2f const inv = rcp_(det);
+  v2f const ovx = ox - p0x, ovy = oy - p0y, ovz = oz - p0z;
+  v2f const qx = fma_(ovy, e0z, -(ovz * e0y));
+  v2f const qy = fma_(ovz, e0x, -(ovx * e0z));
+  v2f const qz = fma_(ovx, e0y, -(ovy * e0x));
   u = inv * fma_(cz, ovz, fma_(cy, ovy, cx * ovx));
   v = inv * fma_(qz, dz, fma_(qy, dy, qx * dx));
   tt = inv * fma_(qz, e1z, fma_(qy, e1y, qx * e1x));

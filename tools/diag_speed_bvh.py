@@ -18,3 +18,8 @@ with pkg.Renderer(0) as r:
     ms, n = r.kernel_time(reset=True)
     st = r.render_stats(1, sample_offset=2 * spp)
     print(f"{ms / n:9.3f} ms per launch  {res * res * spp / (ms / n) / 1e3:9.1f} Msamples/s", {k: round(v / st['samples'], 2) for k, v in st.items()})
+    pr = r.render_profile(32, sample_offset=2 * spp + 1, region=(256, 256, 768, 768))
+    n = pr["samples"]
+    print({k: round(v / n, 3) for k, v in pr.items()})
+    print("wave iterations per sample (x64 lanes):", {k: round(pr[k] / n, 2) for k in ("it_node", "it_leaf", "it_shade", "it_outer", "it_prep")})
+    print("lane utilisation: node %.3f leaf %.3f shade %.3f prep %.3f" % (pr["node_visits"] / max(pr["it_node"], 1), pr["lanes_leaf"] / max(pr["it_leaf"], 1), pr["lanes_shade"] / max(pr["it_shade"], 1), pr["lanes_prep"] / max(pr["it_prep"], 1)))
