@@ -52,6 +52,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "dmt_ctx_create", "dmt_ctx_destroy", "dmt_last_error", "dmt_upload_triangles", "dmt_upload_bsdfs",
     "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_partition", "dmt_set_chunk", "dmt_render_profile",
+    "dmt_upload_envmap", "dmt_clear_envmap", "dmt_envmap_tables", "dmt_test_envmap",
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
     "dmt_render", "dmt_render_stats", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
     "dmt_test_sampler", "dmt_test_camera_rays", "dmt_test_bsdf", "dmt_test_light", "dmt_test_half",
@@ -80,6 +81,21 @@ def bvh_validate(xs, ys, zs):
     nc, d, ml = C.c_int(), C.c_int(), C.c_int()
     rc = lib.dmt_bvh_validate(_p(xs), _p(ys), _p(zs), C.c_size_t(n), C.byref(nc), C.byref(d), C.byref(ml))
     return {"ok": rc == 0, "node_count": nc.value, "depth": d.value, "max_leaf": ml.value}
+
+
+def envmap_tables(rgb):
+    """Host-only: the PiecewiseConstant2D tables dmt_upload_envmap builds for an env map [h, w, 3]."""
+    lib = load_library()
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w = rgb.shape[:2]
+    func, cdf = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+    row_int, m_func, m_cdf = np.zeros(h, np.float32), np.zeros(h, np.float32), np.zeros(h, np.float32)
+    m_int = C.c_float()
+    rc = lib.dmt_envmap_tables(_p(rgb), int(w), int(h), _p(func), _p(cdf), _p(row_int), _p(m_func), _p(m_cdf),
+                               C.byref(m_int))
+    if rc != 0:
+        raise DmtError(f"dmt_envmap_tables failed ({rc})")
+    return dict(func=func, cdf=cdf, row_int=row_int, m_func=m_func, m_cdf=m_cdf, m_int=np.float32(m_int.value))
 
 
 class Renderer:
@@ -149,6 +165,32 @@ class Renderer:
         self.upload_bsdfs(scene.bsdfs)
         self.upload_lights(scene.lights, scene.inf_lights)
         self.set_camera(scene.camera)
+        if getattr(scene, "env_rgb", None) is not None:
+            self.upload_envmap(scene.env_rgb, scene.env_quat, scene.env_scale)
+        else:
+            self.clear_envmap()
+
+    def upload_envmap(self, rgb, quat=(0, 0, 0, 1), scale=1.0):
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        h, w = rgb.shape[:2]
+        q = np.ascontiguousarray(quat, np.float32)
+        self._check(self._lib.dmt_upload_envmap(self._ctx, _p(rgb), int(w), int(h), _p(q), C.c_float(scale)),
+                    "dmt_upload_envmap")
+
+    def clear_envmap(self):
+        self._check(self._lib.dmt_clear_envmap(self._ctx), "dmt_clear_envmap")
+
+    def test_envmap(self, u2, wi):
+        u2, wi = _f32(u2).reshape(-1, 2), _f32(wi).reshape(-1, 3)
+        n = u2.shape[0]
+        assert wi.shape[0] == n
+        out = dict(wi=np.zeros((n, 3), np.float32), pdf=np.zeros(n, np.float32), uv=np.zeros((n, 2), np.float32),
+                   Le=np.zeros((n, 3), np.float32), ok=np.zeros(n, np.int32), Le_dir=np.zeros((n, 3), np.float32),
+                   pdf_dir=np.zeros(n, np.float32))
+        self._check(self._lib.dmt_test_envmap(self._ctx, n, _p(u2), _p(wi), _p(out["wi"]), _p(out["pdf"]), _p(out["uv"]),
+                                              _p(out["Le"]), _p(out["ok"]), _p(out["Le_dir"]), _p(out["pdf_dir"])),
+                    "dmt_test_envmap")
+        return out
 
     def set_limits(self, max_depth):
         self._check(self._lib.dmt_set_limits(self._ctx, int(max_depth)), "dmt_set_limits")

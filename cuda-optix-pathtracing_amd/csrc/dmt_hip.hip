@@ -29,6 +29,7 @@
 #include "../../include/dmt_hip.h"
 #include "pt_device.hpp"
 #include "bvh_device.hpp"
+#include "envmap.hpp"
 
 using namespace dmt;
 
@@ -55,6 +56,7 @@ struct RenderParams {
   uint32_t* tileDone;      // [numItems] chunks completed per owned tile (in-launch ordering of a tile's chunks)
   uint32_t* errorFlag;     // set if a bounded wait gives up
   int maxDepth;
+  EnvView env;                // A18 env map (w == 0: none); read by the *_env kernels only
   unsigned long long* stats;  // stats build only: samples, closest rays, shadow rays, node visits, triangle tests, bounces
 };
 
@@ -91,6 +93,15 @@ DMT_DEV BvhView load_bvh(KArgs k) {
   return b;
 }
 
+DMT_DEV EnvView load_env(KArgs k) {
+  k = kargs(k);
+  EnvView e;
+  e.func = k->env.func, e.cdf = k->env.cdf, e.rowInt = k->env.rowInt, e.mFunc = k->env.mFunc, e.mCdf = k->env.mCdf;
+  e.rgb = k->env.rgb, e.mInt = k->env.mInt, e.w = k->env.w, e.h = k->env.h;
+  e.qx = k->env.qx, e.qy = k->env.qy, e.qz = k->env.qz, e.qw = k->env.qw;
+  return e;
+}
+
 struct PathState {
   RayPair rp;       // .x = current path's ray, .y = pending shadow ray
   f3 beta, L;
@@ -102,6 +113,8 @@ struct PathState {
   float smax;
   Sampler rng;
   uint32_t sidx;    // where the current sample's radiance goes (staging index, megakernel only)
+  float lastPdf;    // env-map kernels only: pdf / delta flag of the bounce that produced the current ray
+  bool lastSpecular;
 };
 // cold per-lane values in LDS, [field][thread]: pending NEE contribution C (0..2) and the parked
 // radiance Lfin of a finished sample (3..5) with its staging index (6); each is touched once per ray pass at most
@@ -150,9 +163,22 @@ DMT_DEV void path_begin(PathState& st, CameraXf const& cam, SamplerParams const&
 // Everything between two ray casts (T/megakernel/megakernel.cu:135-295).  Returns true when the
 // path ends.  May leave a pending shadow ray (st.hasShadow) whose contribution st.C is added once
 // visibility is known.
+template <bool ENV = false>
 DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv) {
   SceneView const sc = load_scene(k);
   int const maxDepth = kargs(k)->maxDepth;
+  if constexpr (ENV) {
+    if (bestTri < 0) {  // A18: the env map seen by a path ray, MIS against NEE (core-render.cpp:154-163)
+      EnvView const env = load_env(k);
+      float pdfLight = 0.f;
+      f3 const Le = env_eval_dir(env, ray_dir(st), pdfLight);
+      if (st.depth == 0 || st.lastSpecular)
+        st.L = st.L + st.beta * Le;
+      else
+        st.L = st.L + st.beta * (st.lastPdf / (st.lastPdf + pdfLight)) * Le;
+      return true;
+    }
+  }
   if (bestTri < 0) {  // miss: constant environment, no MIS (megakernel.cu:135-151)
     if (sc.infLightCount > 0) {
       uint32_t const li = pick_index(st.rng.get1D(), sc.infLightCount);
@@ -170,12 +196,32 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
   Bsdf const b = bsdf_prepare(sc.bsdfs[hit.matId], hit.normal, wo);  // :165-166
 
   // next-event estimation (:170-241)
-  float const uLight = st.rng.get1D();
+  float uLight = st.rng.get1D();
   f2 const uLight2 = st.rng.get2D();
-  if (sc.lightCount > 0) {
+  bool envNee = false;
+  if constexpr (ENV) {  // A18: env map with probability 1/2, the light list otherwise (core-render.cpp:290-299)
+    envNee = uLight < 0.5f;
+    uLight = envNee ? uLight : (uLight - 0.5f) * 2.f;
+    if (envNee) {
+      EnvView const env = load_env(k);
+      EnvSampleDev const es = env_sample(env, uLight2);
+      if (es.ok) {
+        float bsdfPdf = 0.f;
+        f3 const f = eval_bsdf(b, wo, es.wi, hit.normal, hit.normal, bsdfPdf) * b.weight;
+        f3 const Le = env_eval_uv(env, es.uv);
+        if (!is_zero(f) && max3(Le) > 0.f) {  // core-render.cpp:357-369: Le f / (pdfLight pmf + pdfBsdf), pmf = 1/2
+          put_C(st.beta * (Le * f / (es.pdf * 0.5f + bsdfPdf)));
+          set_shadow_ray(st, offset_ray_origin(hit.pos, hit.error, hit.normal, es.wi), es.wi);
+          st.smax = kInf;
+          st.hasShadow = true;
+        }
+      }
+    }
+  }
+  if (!envNee && sc.lightCount > 0) {
     uint32_t const li = pick_index(uLight, sc.lightCount);
     Rec32 const light = sc.lights[li];
-    float const pmf = 1.f / float(sc.lightCount);
+    float const pmf = (ENV ? 0.5f : 1.f) / float(sc.lightCount);
     LightSample const ls = sample_light(light, hit.pos, uLight2, st.lastT, hit.normal);
     if (ls.valid()) {
       float bsdfPdf = 0.f;
@@ -202,6 +248,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
   BsdfSample const bs = sample_bsdf(b, wo, hit.normal, hit.normal, u2, uc);
   if (!bs.valid()) return true;
   st.lastT = bs.refract;
+  if constexpr (ENV) st.lastPdf = bs.pdf, st.lastSpecular = bs.delta;
   set_ray(st, offset_ray_origin(hit.pos, hit.error, hit.normal, bs.wi), bs.wi);
   st.beta = st.beta * (bs.f * fabsf(dot(bs.wi, hit.normal)) / bs.pdf);
   float const rrBeta = max3(st.beta * bs.eta);
@@ -299,11 +346,11 @@ DMT_DEV void trace_pair_bvh(KArgs k, PathState const& st, bool doC, bool doS, ui
 
 // One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
 // sink(L, sidx) is called once per completed sample with the index the sample was started with.
-template <class Sink>
+template <bool ENV = false, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink);
 
-template <bool BVH, bool STATS = false, class Sink>
+template <bool BVH, bool STATS = false, bool ENV = false, class Sink>
 DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneStats* ls = nullptr) {
   bool const doC = st.active;
   bool const doS = st.hasShadow;
@@ -315,11 +362,11 @@ DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneS
   else
     trace_pair_brute(k, st, doC, doS, bestTri, bu, bv, occluded);
   if constexpr (STATS) ls->bounces += (doC && bestTri >= 0 && st.depth < kargs(k)->maxDepth) ? 1u : 0u;
-  lane_finish(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
+  lane_finish<ENV>(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
 }
 
 // Second half of a ray pass: resolve the shadow ray (in the reference's accumulation order), then shade.
-template <class Sink>
+template <bool ENV, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink) {
   if (doS) {
@@ -334,7 +381,7 @@ DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri
     }
   }
   if (doC) {
-    if (path_shade(k, st, bestTri, bu, bv)) {
+    if (path_shade<ENV>(k, st, bestTri, bu, bv)) {
       st.active = false;
       if (st.hasShadow) {  // last NEE still untraced: park the sample, the lane may start the next
         put_Lfin(st.L);
@@ -676,7 +723,7 @@ DMT_DEV void flush_stats(KArgs Pk, LaneStats const& ls) {
   }
 }
 
-template <bool BVH, bool STATS = false>
+template <bool BVH, bool STATS = false, bool ENV = false>
 DMT_DEV void megakernel_body() {
   KArgs const Pk = kargs_base();
   LaneStats ls;
@@ -707,7 +754,7 @@ DMT_DEV void megakernel_body() {
           }
         }
       }
-      lane_step<BVH, STATS>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
+      lane_step<BVH, STATS, ENV>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
     }
   }
   flush_stats<STATS>(Pk, ls);
@@ -722,7 +769,7 @@ DMT_DEV void megakernel_body() {
 // shading runs for all waiting lanes at once when at least DMT_BVH_SHADE_THRESHOLD of them are waiting (or
 // nobody is traversing).  Incoherent rays take very different numbers of steps; with a pass-synchronous
 // loop the wave ran at 14 % lane utilisation.
-template <bool STATS = false>
+template <bool STATS = false, bool ENV = false>
 DMT_DEV void megakernel_body_bvh() {
   KArgs const Pk = kargs_base();
   LaneStats ls;
@@ -813,7 +860,7 @@ DMT_DEV void megakernel_body_bvh() {
       if constexpr (STATS) ++ls.itShade, ls.lanesShade += tv.phase == TR_DONE ? 1u : 0u;
       if (tv.phase == TR_DONE) {
         if constexpr (STATS) ls.bounces += (tv.doC && tv.bestTri >= 0 && st.depth < kargs(Pk)->maxDepth) ? 1u : 0u;
-        lane_finish(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
+        lane_finish<ENV>(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
         tv.phase = TR_IDLE;
       }
     }
@@ -828,6 +875,10 @@ __global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD_BVH) k_megakernel_
 // same kernel with per-lane work counters (node visits, triangle tests, rays, bounces): feeds the
 // algorithmic-bytes model of the BVH path; never on the timed path
 __global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats(RenderParams P) { megakernel_body_bvh<true>(); }
+// A18: the same two kernels with the env-map light compiled in (dmt_upload_envmap selects them).  Separate
+// instantiations, so that the register allocation of the default kernels is not touched.
+__global__ void __launch_bounds__(256, 3) k_megakernel_env(RenderParams P) { megakernel_body<false, false, true>(); }
+__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_env(RenderParams P) { megakernel_body_bvh<false, true>(); }
 
 // ---------------------------------------------------------------------------------------------
 // device unit-test kernels
@@ -845,11 +896,35 @@ __global__ void k_test_trace(RenderParams P, bool useBvh, int n, int32_t const* 
   uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
   for (;;) {
     if (!__any(st.active || st.hasShadow)) break;
-    if (useBvh)
+    bool const useEnv = kargs(k)->env.w > 0;
+    if (useEnv) {
+      if (useBvh)
+        lane_step<true, false, true>(k, gtid, st, store);
+      else
+        lane_step<false, false, true>(k, gtid, st, store);
+    } else if (useBvh) {
       lane_step<true>(k, gtid, st, store);
-    else
+    } else {
       lane_step<false>(k, gtid, st, store);
+    }
   }
+}
+
+// A18 probes: env-map sampling (u2 -> wi, pdf, uv, Le by uv) and evaluation by direction (wi -> Le, pdf)
+__global__ void k_test_envmap(EnvView env, int n, float const* u2, float const* wiIn, float* wi3, float* pdf, float* uv2,
+                              float* Le3, int32_t* ok, float* LeDir3, float* pdfDir) {
+  int const i = int(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  EnvSampleDev const es = env_sample(env, f2{u2[2 * i], u2[2 * i + 1]});
+  f3 const Le = env_eval_uv(env, es.uv);
+  wi3[3 * i] = es.wi.x, wi3[3 * i + 1] = es.wi.y, wi3[3 * i + 2] = es.wi.z;
+  pdf[i] = es.pdf, uv2[2 * i] = es.uv.x, uv2[2 * i + 1] = es.uv.y;
+  Le3[3 * i] = Le.x, Le3[3 * i + 1] = Le.y, Le3[3 * i + 2] = Le.z;
+  ok[i] = es.ok ? 1 : 0;
+  float p = 0.f;
+  f3 const Ld = env_eval_dir(env, mk3(wiIn[3 * i], wiIn[3 * i + 1], wiIn[3 * i + 2]), p);
+  LeDir3[3 * i] = Ld.x, LeDir3[3 * i + 1] = Ld.y, LeDir3[3 * i + 2] = Ld.z;
+  pdfDir[i] = p;
 }
 
 // single path with a per-bounce log {tri, pos3, beta3, L3 (before shading), depth, dim}
@@ -1042,6 +1117,9 @@ struct dmt_ctx {
   int bvhDepth = 0;
   uint32_t bvhNodeCount = 0;
   int blocksPerCUBvh = 0;
+  int blocksPerCUEnv = 0, blocksPerCUBvhEnv = 0;
+  float* d_env = nullptr;  // A18: one allocation holding the five tables and the image
+  EnvView env{};           // env.w == 0: no env map
   bool haveTris = false, haveBsdfs = false, haveLights = false, haveCamera = false;
   // camera
   dmt_camera cam{};
@@ -1172,7 +1250,14 @@ RenderParams baseParams(dmt_ctx const* c, size_t threads) {
   P.cam = c->xf;
   P.sp = c->sp;
   P.maxDepth = c->maxDepth;
+  P.env = c->env;
   return P;
+}
+
+int blocksPerCuOf(dmt_ctx const* c) {
+  bool const env = c->env.w > 0;
+  if (c->accel == DMT_ACCEL_BVH) return env ? c->blocksPerCUBvhEnv : c->blocksPerCUBvh;
+  return env ? c->blocksPerCUEnv : c->blocksPerCU;
 }
 
 template <class T>
@@ -1299,6 +1384,11 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
   int bpcBvh = 0;
   if (e == hipSuccess)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpcBvh, reinterpret_cast<void const*>(k_megakernel_bvh), 256, 0);
+  int bpcEnv = 0, bpcBvhEnv = 0;
+  if (e == hipSuccess)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpcEnv, reinterpret_cast<void const*>(k_megakernel_env), 256, 0);
+  if (e == hipSuccess)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpcBvhEnv, reinterpret_cast<void const*>(k_megakernel_bvh_env), 256, 0);
   if (e != hipSuccess) {
     g_createError = std::string("dmt_ctx_create: ") + hipGetErrorString(e);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -1309,6 +1399,8 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
   ctx->cuCount = prop.multiProcessorCount;
   ctx->blocksPerCU = bpc > 0 ? bpc : 1;
   ctx->blocksPerCUBvh = bpcBvh > 0 ? bpcBvh : 1;
+  ctx->blocksPerCUEnv = bpcEnv > 0 ? bpcEnv : 1;
+  ctx->blocksPerCUBvhEnv = bpcBvhEnv > 0 ? bpcBvhEnv : 1;
   if (char const* e2 = std::getenv("DMT_SUB_SHIFT")) {  // scheduling experiments only: results do not depend on it
     int const v = std::atoi(e2);
     ctx->subShift = v < 0 ? -1 : (v > 2 ? 2 : v);
@@ -1333,6 +1425,7 @@ int dmt_ctx_destroy(dmt_ctx* ctx) {
   (void)hipFree(ctx->d_counter);
   (void)hipFree(ctx->d_tileDone);
   (void)hipFree(ctx->d_stage);
+  (void)hipFree(ctx->d_env);
   (void)hipFree(ctx->d_bvhNodes);
   (void)hipFree(ctx->d_trisBvh);
   (void)hipFree(ctx->d_overflow);
@@ -1566,7 +1659,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   P.maxDepth = ctx->maxDepth;
   if (P.numItems == 0) return DMT_OK;
   {  // fewer owned tiles than ~4 per resident wave: schedule row bands of the tiles instead of whole tiles
-    uint32_t const waves = uint32_t(ctx->cuCount) * uint32_t(ctx->accel == DMT_ACCEL_BVH ? ctx->blocksPerCUBvh : ctx->blocksPerCU) * 4u;
+    uint32_t const waves = uint32_t(ctx->cuCount) * uint32_t(blocksPerCuOf(ctx)) * 4u;
     P.subShift = ctx->subShift >= 0 ? uint32_t(ctx->subShift) : 0u;
     if (ctx->subShift < 0)
       while (P.subShift < 2u && (uint64_t(P.numItems) << P.subShift) < 4ull * waves) ++P.subShift;
@@ -1591,7 +1684,9 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
 
   bool const useBvh = ctx->accel == DMT_ACCEL_BVH;
   uint32_t const wavesWanted = P.numItems * P.numChunks < P.numItems ? P.numItems : P.numItems * P.numChunks;
-  uint32_t blocks = uint32_t(ctx->cuCount) * uint32_t(useBvh ? ctx->blocksPerCUBvh : ctx->blocksPerCU);
+  uint32_t blocks = uint32_t(ctx->cuCount) * uint32_t(blocksPerCuOf(ctx));
+  bool const useEnv = ctx->env.w > 0;
+  P.env = ctx->env;
   uint32_t const blocksNeeded = (wavesWanted + 3) / 4;
   if (blocks > blocksNeeded) blocks = blocksNeeded;
   if (blocks == 0) blocks = 1;
@@ -1618,7 +1713,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
   if (useBvh) {
     if (!ctx->haveBvh) return fail(ctx, DMT_ERR_STATE, "dmt_render: BVH not built");
-    int const rcO = ensureOverflow(ctx, size_t(ctx->cuCount) * size_t(ctx->blocksPerCUBvh) * 256);
+    int const rcO = ensureOverflow(ctx, size_t(ctx->cuCount) * size_t(blocksPerCuOf(ctx) > ctx->blocksPerCUBvh ? blocksPerCuOf(ctx) : ctx->blocksPerCUBvh) * 256);
     if (rcO) return rcO;
     P.bvh = bvhView(ctx, size_t(blocks) * 256);
     if (stats6) {
@@ -1634,7 +1729,12 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
       HIP_TRY(ctx, e);
       return DMT_OK;
     }
-    hipLaunchKernelGGL(k_megakernel_bvh, dim3(blocks), dim3(256), 0, ctx->stream, P);
+    if (useEnv)
+      hipLaunchKernelGGL(k_megakernel_bvh_env, dim3(blocks), dim3(256), 0, ctx->stream, P);
+    else
+      hipLaunchKernelGGL(k_megakernel_bvh, dim3(blocks), dim3(256), 0, ctx->stream, P);
+  } else if (useEnv) {
+    hipLaunchKernelGGL(k_megakernel_env, dim3(blocks), dim3(256), 0, ctx->stream, P);
   } else {
     hipLaunchKernelGGL(k_megakernel, dim3(blocks), dim3(256), 0, ctx->stream, P);
   }
@@ -1727,6 +1827,94 @@ int dmt_sync(dmt_ctx* ctx) {
   return DMT_OK;
 }
 
+int dmt_envmap_tables(const float* rgb, int width, int height, float* func, float* cdf, float* row_integral,
+                      float* marginal_func, float* marginal_cdf, float* marginal_integral) {
+  if (!rgb || width < 8 || height < 8 || (width & (width - 1)) || (height & (height - 1)) || !func || !cdf ||
+      !row_integral || !marginal_func || !marginal_cdf || !marginal_integral)
+    return DMT_ERR_INVALID;
+  envmap::Tables const t = envmap::build(rgb, width, height);
+  memcpy(func, t.func.data(), t.func.size() * 4), memcpy(cdf, t.cdf.data(), t.cdf.size() * 4);
+  memcpy(row_integral, t.rowInt.data(), t.rowInt.size() * 4);
+  memcpy(marginal_func, t.mFunc.data(), t.mFunc.size() * 4), memcpy(marginal_cdf, t.mCdf.data(), t.mCdf.size() * 4);
+  *marginal_integral = t.mInt;
+  return DMT_OK;
+}
+
+int dmt_clear_envmap(dmt_ctx* ctx) {
+  if (!ctx) return DMT_ERR_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->d_env) (void)hipFree(ctx->d_env);
+  ctx->d_env = nullptr;
+  ctx->env = EnvView{};
+  return DMT_OK;
+}
+
+int dmt_upload_envmap(dmt_ctx* ctx, const float* rgb, int width, int height, const float* quat_xyzw, float scale) {
+  if (!ctx || !rgb || !quat_xyzw) return DMT_ERR_INVALID;
+  // the reference asserts powers of two and width == 2 * height (core-light.cpp:116); 8 = one AVX2 block of its CDF
+  if (width < 8 || height < 8 || (width & (width - 1)) || (height & (height - 1)) || width != 2 * height)
+    return fail(ctx, DMT_ERR_INVALID, "dmt_upload_envmap: resolution must be powers of two >= 8 with width == 2 * height");
+  float const len = std::sqrt(quat_xyzw[0] * quat_xyzw[0] + quat_xyzw[1] * quat_xyzw[1] + quat_xyzw[2] * quat_xyzw[2] +
+                              quat_xyzw[3] * quat_xyzw[3]);
+  if (!(len > 0.f)) return fail(ctx, DMT_ERR_INVALID, "dmt_upload_envmap: zero quaternion");
+  (void)scale;  // stored by the reference and never applied (core-light.cpp:115, :444-452)
+  int rc = dmt_clear_envmap(ctx);
+  if (rc) return rc;
+  envmap::Tables const t = envmap::build(rgb, width, height);
+  size_t const wh = size_t(width) * size_t(height), h = size_t(height);
+  size_t const total = 2 * wh + 3 * h + 3 * wh;
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_env), total * sizeof(float)));
+  float* p = ctx->d_env;
+  EnvView e{};
+  auto put = [&](float const* src, size_t n) -> float const* {
+    float* dst = p;
+    p += n;
+    return hipMemcpy(dst, src, n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? dst : nullptr;
+  };
+  e.func = put(t.func.data(), wh), e.cdf = put(t.cdf.data(), wh), e.rowInt = put(t.rowInt.data(), h);
+  e.mFunc = put(t.mFunc.data(), h), e.mCdf = put(t.mCdf.data(), h), e.rgb = put(rgb, 3 * wh);
+  if (!e.func || !e.cdf || !e.rowInt || !e.mFunc || !e.mCdf || !e.rgb) {
+    (void)dmt_clear_envmap(ctx);
+    return fail(ctx, DMT_ERR_HIP, "dmt_upload_envmap: copy failed");
+  }
+  e.mInt = t.mInt, e.w = width, e.h = height;
+  e.qx = quat_xyzw[0] / len, e.qy = quat_xyzw[1] / len, e.qz = quat_xyzw[2] / len, e.qw = quat_xyzw[3] / len;
+  ctx->env = e;
+  return DMT_OK;
+}
+
+int dmt_test_envmap(dmt_ctx* ctx, int n, const float* u2, const float* wi_in3, float* wi3, float* pdf, float* uv2,
+                    float* Le3, int32_t* ok, float* Le_dir3, float* pdf_dir) {
+  if (!ctx || n <= 0 || !u2 || !wi_in3 || !wi3 || !pdf || !uv2 || !Le3 || !ok || !Le_dir3 || !pdf_dir) return DMT_ERR_INVALID;
+  if (ctx->env.w <= 0) return fail(ctx, DMT_ERR_STATE, "dmt_test_envmap: no env map uploaded");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t const N = size_t(n);
+  float* d = nullptr;  // u2(2) wiIn(3) wi(3) pdf(1) uv(2) Le(3) ok(1) LeDir(3) pdfDir(1) = 19 words per case
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), N * 19 * sizeof(float)));
+  float *du = d, *dwin = d + 2 * N, *dwi = d + 5 * N, *dpdf = d + 8 * N, *duv = d + 9 * N, *dLe = d + 11 * N;
+  int32_t* dok = reinterpret_cast<int32_t*>(d + 14 * N);
+  float *dLd = d + 15 * N, *dpd = d + 18 * N;
+  hipError_t e = hipMemcpy(du, u2, N * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dwin, wi_in3, N * 12, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_test_envmap, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->env, n, du, dwin, dwi, dpdf, duv,
+                       dLe, dok, dLd, dpd);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpy(wi3, dwi, N * 12, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(pdf, dpdf, N * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(uv2, duv, N * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(Le3, dLe, N * 12, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(ok, dok, N * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(Le_dir3, dLd, N * 12, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(pdf_dir, dpd, N * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(ctx, e);
+  return DMT_OK;
+}
+
 int dmt_set_chunk(dmt_ctx* ctx, uint32_t samples_per_item) {
   if (!ctx) return DMT_ERR_INVALID;
   ctx->chunkSpp = samples_per_item;
@@ -1759,7 +1947,7 @@ int dmt_kernel_info(dmt_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* b
   if (vgprs) *vgprs = attr.numRegs;
   if (sgprs) *sgprs = 0;
   if (lds_bytes) *lds_bytes = int(attr.sharedSizeBytes);
-  if (blocks_per_cu) *blocks_per_cu = useBvh ? ctx->blocksPerCUBvh : ctx->blocksPerCU;
+  if (blocks_per_cu) *blocks_per_cu = blocksPerCuOf(ctx);
   if (cu_count) *cu_count = ctx->cuCount;
   return DMT_OK;
 }

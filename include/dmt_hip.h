@@ -93,6 +93,22 @@ int dmt_set_accel(dmt_ctx* ctx, int mode);
 /* tile partition for multi-GPU rendering: this context renders only the 8x8-pixel tiles whose
  * index (row-major over the tile grid) is congruent to `rank` modulo `world`.  Default 0 of 1. */
 int dmt_set_partition(dmt_ctx* ctx, int rank, int world);
+/* A18 -- environment-map light of the reference's CPU renderer (src/core/private/core-light.cpp:84-117,394-491;
+ * PiecewiseConstant2D src/core/private/core-math.cu:385-675; MIS rules src/core/private/core-render.cpp:154-163,
+ * 290-299,357-369), added to the megakernel path: rgb = height x width x 3 floats (equirectangular, powers of two,
+ * width == 2 * height), quat_xyzw = lightFromRender.  While an env map is set, rays that leave the scene see the map
+ * (MIS against NEE) instead of the constant environment records, and NEE samples the map with probability 1/2.
+ * `scale` is accepted for signature parity; the reference stores it and never applies it. */
+int dmt_upload_envmap(dmt_ctx* ctx, const float* rgb, int width, int height, const float* quat_xyzw, float scale);
+int dmt_clear_envmap(dmt_ctx* ctx);
+/* host only (no GPU needed): the sampling tables dmt_upload_envmap builds; func/cdf: height*width floats each,
+ * row_integral / marginal_func / marginal_cdf: height floats each */
+int dmt_envmap_tables(const float* rgb, int width, int height, float* func, float* cdf, float* row_integral,
+                      float* marginal_func, float* marginal_cdf, float* marginal_integral);
+/* device probes of the env-map functions: per case u2 -> sampled wi3, pdf, uv2, Le3 (by uv), ok; and
+ * wi_in3 -> Le_dir3, pdf_dir (evaluation by direction) */
+int dmt_test_envmap(dmt_ctx* ctx, int n, const float* u2, const float* wi_in3, float* wi3, float* pdf, float* uv2,
+                    float* Le3, int32_t* ok, float* Le_dir3, float* pdf_dir);
 /* samples per work item inside one dmt_render pass (0 = automatic, the default: 1 024 path samples per item; at most 512).  Purely a
  * scheduling knob: a pixel's samples are folded in index order for any value, the film is bit-identical. */
 int dmt_set_chunk(dmt_ctx* ctx, uint32_t samples_per_item);

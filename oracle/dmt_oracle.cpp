@@ -1365,6 +1365,165 @@ void prepareBSDF(Rec32* b, V3 ns, V3 wo, int /*transmissionCount*/) {  // :909-1
 // ------------------------------------------------------------------------------------
 // scene + integrator                               T/megakernel/megakernel.cu:53-322
 // ------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------
+// A18: environment-map light of the reference's CPU renderer
+//   PiecewiseConstant1D/2D       src/core/private/core-math.cu:385-675
+//   EnvLight, sample, eval       src/core/private/core-light.cpp:84-117,394-491
+//   MIS rules                    src/core/private/core-render.cpp:154-163,290-299,357-369
+// Restated with the reference's quirks: the 1-D CDF is INCLUSIVE (cdf[i] = sum_{j<=i}) and is summed in the
+// AVX2 block order of core-math.cu:440-485; sample() never returns the last bin and prices bin `off` with
+// func[off] although the inclusive CDF puts u in bin off+1 (core-math.cu:566-595); the sampling direction
+// uses phi = clamp(1 - 2 pi u, -pi, pi) and theta = pi v while evaluation by direction uses the flipped
+// v = 1 - theta/pi (the #define sits in the middle of core-light.cpp, line 468); the light's scale factor is
+// stored and never applied (core-light.cpp:115,444-452).  Quaternion products are glm's Hamilton product
+// (dependency g-truc/glm, fetched by cmake/Dependencies.cmake:50-57, not vendored).
+// ------------------------------------------------------------------------------------
+struct Pc1D {
+  std::vector<float> absf, cdf;  // both n entries
+  float integral = 0.f;
+};
+inline void pc1dBuild(float const* f, uint32_t n, float mn, float mx, Pc1D& out) {
+  out.absf.resize(n), out.cdf.resize(n);
+  for (uint32_t i = 0; i < n; ++i) out.absf[i] = fabsf(f[i]);
+  float const fac = (mx - mn) / float(n);
+  float carry = 0.f;
+  uint32_t const nb = n & ~7u;
+  for (uint32_t b = 0; b < nb; b += 8) {  // core-math.cu:447-481: in-lane prefix sums, lane 0 total into lane 1, carry
+    float x[8];
+    for (int j = 0; j < 8; ++j) x[j] = f[b + uint32_t(j)] * fac;
+    for (int l = 0; l < 8; l += 4) {
+      float const a0 = x[l], a1 = x[l + 1] + x[l], a2 = x[l + 2] + x[l + 1], a3 = x[l + 3] + x[l + 2];
+      x[l] = a0, x[l + 1] = a1, x[l + 2] = a2 + a0, x[l + 3] = a3 + a1;
+    }
+    float const lane0 = x[3];
+    for (int j = 4; j < 8; ++j) x[j] = x[j] + lane0;
+    for (int j = 0; j < 8; ++j) out.cdf[b + uint32_t(j)] = x[j] + carry;
+    carry = out.cdf[b + 7];
+  }
+  for (uint32_t i = nb; i < n; ++i)  // core-math.cu:484-490 (unscaled; only n < 8 or non-multiples reach it)
+    out.cdf[i] = (i ? out.cdf[i - 1] : 0.f) + f[i];
+  out.integral = out.cdf[n - 1];
+  bool const zero = fabsf(out.integral) <= std::numeric_limits<float>::epsilon();  // fl::nearZero
+  float const fac2 = 1.0f / (zero ? float(n) : out.integral);                        // fl::rcp
+  if (zero)
+    for (uint32_t i = 0; i < n; ++i) out.cdf[i] = float(i) * fac2;
+  else
+    for (uint32_t i = 0; i < n; ++i) out.cdf[i] *= fac2;
+}
+inline int32_t findIntervalLessThan(int32_t sz, float const* cdf, float u) {  // core-math.cu:553-564
+  int32_t size = sz - 2, first = 1;
+  while (size > 0) {
+    int32_t const half = size >> 1, middle = first + half;
+    bool const pred = cdf[middle] <= u;
+    first = pred ? middle + 1 : first;
+    size = pred ? size - (half + 1) : half;
+  }
+  int32_t const r = first - 1;
+  return r < 0 ? 0 : (r > sz - 2 ? sz - 2 : r);
+}
+inline float pc1dSample(float const* absf, float const* cdf, int32_t n, float integral, float u, float* pdf,
+                        int32_t* offset) {  // core-math.cu:566-582, domain [0,1]
+  int32_t const off = findIntervalLessThan(n, cdf, u);
+  *offset = off;
+  float du = u - cdf[off];
+  if (cdf[off + 1] - cdf[off] > 0) du /= cdf[off + 1] - cdf[off];
+  *pdf = integral > 0 ? absf[off] / integral : 0.f;
+  float const delta = (float(off) + du) / float(n);
+  return delta == 0.f ? 0.f : (1.f - 0.f) * delta + 0.f;  // fl::lerp(delta, min = 0, max = 1)
+}
+struct EnvMap {
+  int w = 0, h = 0;
+  float const* rgb = nullptr;       // h x w x 3
+  std::vector<float> func, cdf;     // conditional rows, h x w each
+  std::vector<float> rowInt;        // integral of each row
+  Pc1D marginal;                    // over rows
+  float q[4] = {0, 0, 0, 1};        // lightFromRender, normalised (x, y, z, w)
+  float scale = 1.f;
+};
+inline void envBuild(float const* rgb, int w, int h, float const* quat, float scale, EnvMap& e) {
+  e.w = w, e.h = h, e.rgb = rgb, e.scale = scale;
+  e.func.resize(size_t(w) * h), e.cdf.resize(size_t(w) * h), e.rowInt.resize(size_t(h));
+  std::vector<float> row(static_cast<size_t>(w), 0.f);
+  for (int y = 0; y < h; ++y) {  // distributionFromImage: RGB::avg() per texel (core-light.cpp:84-103)
+    for (int x = 0; x < w; ++x) {
+      float const* p = rgb + 3 * (size_t(x) + size_t(y) * size_t(w));
+      row[size_t(x)] = (p[0] + p[1] + p[2]) / 3.f;
+    }
+    Pc1D c;
+    pc1dBuild(row.data(), uint32_t(w), 0.f, 1.f, c);
+    memcpy(&e.func[size_t(y) * w], c.absf.data(), size_t(w) * 4);
+    memcpy(&e.cdf[size_t(y) * w], c.cdf.data(), size_t(w) * 4);
+    e.rowInt[size_t(y)] = c.integral;
+  }
+  pc1dBuild(e.rowInt.data(), uint32_t(h), 0.f, 1.f, e.marginal);
+  float const len = sqrtf(quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2] + quat[3] * quat[3]);
+  for (int i = 0; i < 4; ++i) e.q[i] = quat[i] / len;  // normalize(quat), core-light.cpp:110
+}
+struct Quat {
+  float x, y, z, w;
+};
+inline Quat qmul(Quat p, Quat q) {  // glm::qua operator*
+  return Quat{p.w * q.x + p.x * q.w + p.y * q.z - p.z * q.y, p.w * q.y + p.y * q.w + p.z * q.x - p.x * q.z,
+              p.w * q.z + p.z * q.w + p.x * q.y - p.y * q.x, p.w * q.w - p.x * q.x - p.y * q.y - p.z * q.z};
+}
+inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+struct EnvSample {
+  V3 wi;
+  float pdf;
+  V2 uv;
+  bool ok;
+};
+inline EnvSample envSample(EnvMap const& e, V2 u) {  // envLightSampleFromContext, core-light.cpp:394-442
+  EnvSample r{};
+  float pdfs[2];
+  int32_t iu, iv;
+  float const d1 = pc1dSample(e.marginal.absf.data(), e.marginal.cdf.data(), e.h, e.marginal.integral, u.y, &pdfs[1], &iv);
+  float const d0 = pc1dSample(&e.func[size_t(iv) * e.w], &e.cdf[size_t(iv) * e.w], e.w, e.rowInt[size_t(iv)], u.x, &pdfs[0], &iu);
+  float const mapPdf = pdfs[0] * pdfs[1];
+  r.uv = V2{d0, d1};
+  if (mapPdf == 0.f) return r;
+  float const kPi = 3.14159265358979323846f;
+  float const phi = clampf(1.f - 2.f * kPi * d0, -kPi, kPi);
+  float const theta = clampf(kPi * d1, 0.f, kPi);
+  // cartesianFromSpherical(1, phi, theta), cudautils-numbers.cuh:15-25
+  float const sp = sinf(phi), cp = cosf(phi), st = sinf(theta), ct = cosf(theta);
+  Quat const wl{1.f * sp * ct, 1.f * sp * st, 1.f * cp, 0.f};
+  Quat const q{e.q[0], e.q[1], e.q[2], e.q[3]};
+  Quat const qc{-q.x, -q.y, -q.z, q.w};
+  Quat const wi = qmul(qmul(qc, wl), q);
+  r.wi = v3(wi.x, wi.y, wi.z);
+  r.pdf = mapPdf / (4 * kPi);
+  r.ok = true;
+  return r;
+}
+inline V3 envEvalUv(EnvMap const& e, V2 uv) {  // envLightEval(light, sample), core-light.cpp:444-452
+  int32_t const xi = int32_t(roundf(clampf(uv.x, 0.f, 1.f) * float(e.w - 1)));
+  int32_t const yi = int32_t(roundf(clampf(uv.y, 0.f, 1.f) * float(e.h - 1)));
+  float const* p = e.rgb + 3 * (size_t(xi) + size_t(yi) * size_t(e.w));
+  return v3(p[0], p[1], p[2]);
+}
+inline float pc2dPdf(EnvMap const& e, V2 p) {  // PiecewiseConstant2D::pdf, core-math.cu:628-644
+  int32_t iu = int32_t(p.x * float(e.w)), iv = int32_t(p.y * float(e.h));
+  iu = iu < 0 ? 0 : (iu > e.w - 1 ? e.w - 1 : iu);
+  iv = iv < 0 ? 0 : (iv > e.h - 1 ? e.h - 1 : iv);
+  return e.func[size_t(iv) * e.w + size_t(iu)] / e.marginal.integral;
+}
+inline V3 envEvalDir(EnvMap const& e, V3 wi, float* pdf) {  // envLightEval(light, wi, pdf), core-light.cpp:454-491
+  Quat const q{e.q[0], e.q[1], e.q[2], e.q[3]};
+  Quat const qc{-q.x, -q.y, -q.z, q.w};
+  Quat const wl = qmul(qmul(q, Quat{wi.x, wi.y, wi.z, 0.f}), qc);
+  float const kPi = 3.14159265358979323846f;
+  float const theta = acosf(clampf(wl.z, -1.f, 1.f));
+  float const phi = atan2f(wl.y, wl.x);
+  V2 const uv{0.5f * (1.f + phi / kPi), 1.f - theta / kPi};
+  *pdf = pc2dPdf(e, uv) / (4.f * kPi);
+  int32_t xi = int32_t(uv.x * float(e.w)), yi = int32_t(uv.y * float(e.h));
+  xi = xi < 0 ? 0 : (xi > e.w - 1 ? e.w - 1 : xi);
+  yi = yi < 0 ? 0 : (yi > e.h - 1 ? e.h - 1 : yi);
+  float const* p = e.rgb + 3 * (size_t(xi) + size_t(yi) * size_t(e.w));
+  return v3(p[0], p[1], p[2]);
+}
+
 struct Camera {  // CC/public/cuda-core/types.cuh:101-109 (44 bytes)
   float dir[3];
   float pos[3];
@@ -1385,6 +1544,7 @@ struct Scene {
   uint32_t infLightCount;
   Rec32 const* bsdfs;
   uint32_t bsdfCount;
+  EnvMap const* env = nullptr;  // A18: replaces the constant environment when set
 };
 
 struct Stats {  // algorithmic work counters (SURVEY 8d byte model)
@@ -1428,6 +1588,8 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
   bool lastBounceTransmission = false;
   V3 L = v3(0, 0, 0);
   V3 beta = v3(1, 1, 1);
+  float lastBsdfPdf = 1.f;      // env map only: pdf / delta flag of the bounce that produced the current ray
+  bool specularBounce = false;  // (core-render.cpp:139-143)
   Ray ray = cameraRay(cameraSampleFilm(px, py, rng, cfg.hp), cfg.cameraFromRaster,
                       cfg.renderFromCamera);
   if (st) st->samples++;
@@ -1445,6 +1607,15 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
       }
     }
     if (log) log->push(hitTri, hit.pos, beta, L, depth, rng.dimension);
+    if (!hit.hit && sc.env) {  // A18: env map seen by a path ray, MIS against NEE (core-render.cpp:154-163)
+      float pdfLight = 0.f;
+      V3 const Le = envEvalDir(*sc.env, ray.d, &pdfLight);
+      if (depth == 0 || specularBounce)
+        L += beta * Le;
+      else
+        L += beta * (lastBsdfPdf / (lastBsdfPdf + pdfLight)) * Le;
+      break;
+    }
     if (!hit.hit) {
       if (sc.infLightCount > 0) {  // (reference reads out of bounds when the list is empty)
         uint32_t const li = pickIndex(rng.get1D(), sc.infLightCount);
@@ -1460,12 +1631,38 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
     bsdf = sc.bsdfs[hit.matId];
     prepareBSDF(&bsdf, hit.normal, -ray.d, transmissionCount);
 
-    float const uLight = rng.get1D();
+    float uLight = rng.get1D();
     V2 const uLight2 = rng.get2D();
-    if (sc.lightCount > 0) {
+    bool envNee = false;
+    if (sc.env) {  // A18: env map with probability 1/2, the light list otherwise (core-render.cpp:290-299)
+      envNee = uLight < 0.5f;
+      uLight = envNee ? uLight : (uLight - 0.5f) * 2.f;
+    }
+    if (envNee) {
+      EnvSample const es = envSample(*sc.env, uLight2);
+      if (es.ok) {
+        Ray const shadow{offsetRayOrigin(hit.pos, hit.error, hit.normal, es.wi), es.wi};
+        bool visible = true;
+        if (st) st->shadowRays++;
+        for (uint64_t tri = 0; tri < sc.triCount; ++tri) {
+          if (st) st->triTests++;
+          if (triangleIntersect(sc.xs + 4 * tri, sc.ys + 4 * tri, sc.zs + 4 * tri, shadow).hit) {
+            visible = false;
+            break;
+          }
+        }
+        if (visible) {
+          float bsdfPdf = 0;
+          V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, hit.normal, hit.normal, &bsdfPdf) * bsdfWeight(bsdf);
+          V3 const Le = envEvalUv(*sc.env, es.uv);
+          // core-render.cpp:357-369: Le f / (pdfLight pmf + pdfBsdf), pmf = 1/2
+          if (!isZero(f) && maxComponent(Le) > 0.f) L += beta * (Le * f / (es.pdf * 0.5f + bsdfPdf));
+        }
+      }
+    } else if (sc.lightCount > 0) {
       uint32_t const li = pickIndex(uLight, sc.lightCount);
       Rec32 const& light = sc.lights[li];
-      float const lightPMF = 1.f / sc.lightCount;
+      float const lightPMF = (sc.env ? 0.5f : 1.f) / sc.lightCount;
       LightSample const ls = sampleLight(light, hit.pos, uLight2, lastBounceTransmission, hit.normal);
       if (ls.valid()) {
         Ray const shadow{offsetRayOrigin(hit.pos, hit.error, hit.normal, ls.direction), ls.direction};
@@ -1508,6 +1705,7 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
     if (!bs.valid()) break;
     transmissionCount += bs.refract;
     lastBounceTransmission = bs.refract;
+    lastBsdfPdf = bs.pdf, specularBounce = bs.delta;
     ray.o = offsetRayOrigin(hit.pos, hit.error, hit.normal, bs.wi);
     ray.d = bs.wi;
     beta *= bs.f * fabsf(dot(bs.wi, hit.normal)) / bs.pdf;
@@ -1690,10 +1888,19 @@ struct OracleScene {  // mirrors include/dmt_hip.h's upload calls
   uint32_t infLightCount;
   const void* bsdfs;
   uint32_t bsdfCount;
+  // A18 (optional): equirectangular RGB float image, h x w x 3, w == 2 h, powers of two; quaternion x,y,z,w
+  const float* envRgb;
+  int32_t envW, envH;
+  float envQuat[4];
+  float envScale;
 };
 
-static Scene toScene(OracleScene const* s) {
+static Scene toScene(OracleScene const* s, EnvMap* envStorage = nullptr) {
   Scene sc;
+  if (envStorage && s->envRgb && s->envW > 0 && s->envH > 0) {
+    envBuild(s->envRgb, s->envW, s->envH, s->envQuat, s->envScale, *envStorage);
+    sc.env = envStorage;
+  }
   sc.xs = s->xs, sc.ys = s->ys, sc.zs = s->zs, sc.matId = s->matId, sc.triCount = s->triCount;
   sc.lights = reinterpret_cast<Rec32 const*>(s->lights), sc.lightCount = s->lightCount;
   sc.infLights = reinterpret_cast<Rec32 const*>(s->infLights), sc.infLightCount = s->infLightCount;
@@ -1919,7 +2126,8 @@ int oracle_render(const OracleScene* s, const void* camera44, int maxDepth, int 
                   uint64_t* stats6) {
   Camera cam;
   memcpy(&cam, camera44, sizeof(Camera));
-  Scene const sc = toScene(s);
+  EnvMap env;
+  Scene const sc = toScene(s, &env);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   if (x0 < 0) x0 = 0;
   if (y0 < 0) y0 = 0;
@@ -1968,7 +2176,8 @@ void oracle_trace_samples(const OracleScene* s, const void* camera44, int maxDep
                           float* L3) {
   Camera cam;
   memcpy(&cam, camera44, sizeof(Camera));
-  Scene const sc = toScene(s);
+  EnvMap env;
+  Scene const sc = toScene(s, &env);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   for (int i = 0; i < n; ++i) {
     V3 const L = tracePath(sc, cfg, pxs[i], pys[i], ss[i], nullptr);
@@ -1981,13 +2190,53 @@ int oracle_trace_log(const OracleScene* s, const void* camera44, int maxDepth, i
                      int rtlArgs, float* rec12, int cap, float* Lout3) {
   Camera cam;
   memcpy(&cam, camera44, sizeof(Camera));
-  Scene const sc = toScene(s);
+  EnvMap env;
+  Scene const sc = toScene(s, &env);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   PathLog log;
   log.rec = rec12, log.cap = cap;
   V3 const L = tracePath(sc, cfg, px, py, smp, nullptr, &log);
   Lout3[0] = L.x, Lout3[1] = L.y, Lout3[2] = L.z;
   return log.n;
+}
+
+// --- A18 env map: tables and per-function cases ---------------------------------------------
+// func/cdf: h*w each; rowInt, mFunc, mCdf: h each; mInt: 1
+void oracle_envmap_tables(const float* rgb, int w, int h, float* func, float* cdf, float* rowInt, float* mFunc,
+                          float* mCdf, float* mInt) {
+  float const q[4] = {0, 0, 0, 1};
+  EnvMap e;
+  envBuild(rgb, w, h, q, 1.f, e);
+  memcpy(func, e.func.data(), e.func.size() * 4);
+  memcpy(cdf, e.cdf.data(), e.cdf.size() * 4);
+  memcpy(rowInt, e.rowInt.data(), e.rowInt.size() * 4);
+  memcpy(mFunc, e.marginal.absf.data(), size_t(h) * 4);
+  memcpy(mCdf, e.marginal.cdf.data(), size_t(h) * 4);
+  *mInt = e.marginal.integral;
+}
+// sampling: per case u2 -> wi3, pdf, uv2, Le3 (Le by uv, as NEE uses it), ok
+void oracle_envmap_sample(const float* rgb, int w, int h, const float* quat4, int n, const float* u2, float* wi3,
+                          float* pdf, float* uv2, float* Le3, int32_t* ok) {
+  EnvMap e;
+  envBuild(rgb, w, h, quat4, 1.f, e);
+  for (int i = 0; i < n; ++i) {
+    EnvSample const es = envSample(e, V2{u2[2 * i], u2[2 * i + 1]});
+    V3 const Le = envEvalUv(e, es.uv);
+    wi3[3 * i] = es.wi.x, wi3[3 * i + 1] = es.wi.y, wi3[3 * i + 2] = es.wi.z;
+    pdf[i] = es.pdf, uv2[2 * i] = es.uv.x, uv2[2 * i + 1] = es.uv.y;
+    Le3[3 * i] = Le.x, Le3[3 * i + 1] = Le.y, Le3[3 * i + 2] = Le.z;
+    ok[i] = es.ok ? 1 : 0;
+  }
+}
+// evaluation by direction (what a path ray that leaves the scene sees): Le3, pdf
+void oracle_envmap_eval(const float* rgb, int w, int h, const float* quat4, int n, const float* wi3, float* Le3,
+                        float* pdf) {
+  EnvMap e;
+  envBuild(rgb, w, h, quat4, 1.f, e);
+  for (int i = 0; i < n; ++i) {
+    V3 const Le = envEvalDir(e, v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), &pdf[i]);
+    Le3[3 * i] = Le.x, Le3[3 * i + 1] = Le.y, Le3[3 * i + 2] = Le.z;
+  }
 }
 
 // 8-bit quantisation of the writers            CC/private/host_utils.cu:475-497

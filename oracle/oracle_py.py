@@ -27,6 +27,8 @@ class OracleScene(C.Structure):
         ("lights", C.c_void_p), ("lightCount", C.c_uint32),
         ("infLights", C.c_void_p), ("infLightCount", C.c_uint32),
         ("bsdfs", C.c_void_p), ("bsdfCount", C.c_uint32),
+        ("envRgb", C.c_void_p), ("envW", C.c_int32), ("envH", C.c_int32), ("envQuat", C.c_float * 4),
+        ("envScale", C.c_float),
     ]
 
 
@@ -71,6 +73,16 @@ class Scene:
         self.lights = np.ascontiguousarray(lights, np.uint8).reshape(-1, 32)
         self.inf_lights = np.ascontiguousarray(inf_lights, np.uint8).reshape(-1, 32)
         self.camera = np.ascontiguousarray(camera, np.uint8).reshape(44).copy()
+        self.env_rgb = None            # A18: optional env map, float32 [h, w, 3], w == 2 h, powers of two
+        self.env_quat = np.array([0, 0, 0, 1], np.float32)  # lightFromRender, x y z w
+        self.env_scale = 1.0
+
+    def set_envmap(self, rgb, quat=(0, 0, 0, 1), scale=1.0):
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        h, w = rgb.shape[:2]
+        assert rgb.shape == (h, w, 3) and w == 2 * h and h >= 8 and (h & (h - 1)) == 0
+        self.env_rgb, self.env_quat, self.env_scale = rgb, np.asarray(quat, np.float32), float(scale)
+        return self
 
     @property
     def tri_count(self):
@@ -96,6 +108,10 @@ class Scene:
         s.lights, s.lightCount = _p(self.lights), self.lights.shape[0]
         s.infLights, s.infLightCount = _p(self.inf_lights), self.inf_lights.shape[0]
         s.bsdfs, s.bsdfCount = _p(self.bsdfs), self.bsdfs.shape[0]
+        if self.env_rgb is not None:
+            s.envRgb, s.envH, s.envW = _p(self.env_rgb), self.env_rgb.shape[0], self.env_rgb.shape[1]
+            s.envQuat = (C.c_float * 4)(*[float(v) for v in self.env_quat])
+            s.envScale = self.env_scale
         return s
 
 
@@ -254,6 +270,40 @@ def light_cases(light32, pos, nrm, u2, had_transmission):
     out = np.zeros((n, 14), np.float32)
     lib().oracle_light_cases(_p(light32), n, _p(pos), _p(nrm), _p(u2), _p(ht), _p(out))
     return out
+
+
+def envmap_tables(rgb):
+    """A18: PiecewiseConstant2D tables of an env map -> dict(func, cdf, row_int, m_func, m_cdf, m_int)."""
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w = rgb.shape[:2]
+    func, cdf = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+    row_int, m_func, m_cdf = np.zeros(h, np.float32), np.zeros(h, np.float32), np.zeros(h, np.float32)
+    m_int = C.c_float()
+    lib().oracle_envmap_tables(_p(rgb), w, h, _p(func), _p(cdf), _p(row_int), _p(m_func), _p(m_cdf), C.byref(m_int))
+    return dict(func=func, cdf=cdf, row_int=row_int, m_func=m_func, m_cdf=m_cdf, m_int=np.float32(m_int.value))
+
+
+def envmap_sample(rgb, quat, u2):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w = rgb.shape[:2]
+    u2 = np.ascontiguousarray(u2, np.float32).reshape(-1, 2)
+    n = u2.shape[0]
+    q = np.ascontiguousarray(quat, np.float32)
+    wi, pdf, uv, Le, ok = (np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros((n, 2), np.float32),
+                           np.zeros((n, 3), np.float32), np.zeros(n, np.int32))
+    lib().oracle_envmap_sample(_p(rgb), w, h, _p(q), n, _p(u2), _p(wi), _p(pdf), _p(uv), _p(Le), _p(ok))
+    return dict(wi=wi, pdf=pdf, uv=uv, Le=Le, ok=ok)
+
+
+def envmap_eval(rgb, quat, wi):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w = rgb.shape[:2]
+    wi = np.ascontiguousarray(wi, np.float32).reshape(-1, 3)
+    n = wi.shape[0]
+    q = np.ascontiguousarray(quat, np.float32)
+    Le, pdf = np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+    lib().oracle_envmap_eval(_p(rgb), w, h, _p(q), n, _p(wi), _p(Le), _p(pdf))
+    return dict(Le=Le, pdf=pdf)
 
 
 def pixels_from_film(mean, m2):

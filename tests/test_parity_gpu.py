@@ -546,3 +546,87 @@ def test_cli_writes_reference_named_pngs(renderer, O, tmp_path):
     assert (np.abs(se.astype(int) - b.astype(int)) <= 1).all() and (se != b).mean() < 0.02
     bad = subprocess.run([str(exe), "--spp", "2", "--kspp", "4"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "invalid spp" in bad.stderr      # Config::validate (host_utils.cuh:48-51)
+
+
+# ---------------------------------------------------------------------------------------------
+# A18: environment-map light (semantics of the reference's CPU renderer, core-light.cpp:394-491,
+# core-render.cpp:154-163,290-299,357-369).  No reference-side vectors exist: parity is oracle <-> HIP.
+# ---------------------------------------------------------------------------------------------
+def _envmap(h=32, seed=7):
+    rng = np.random.default_rng(seed)
+    w = 2 * h
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([0.2 + 0.3 * y / h, 0.25 + 0.2 * x / w, 0.4 + 0.0 * x], -1).astype(np.float32)
+    for _ in range(6):
+        img[rng.integers(0, h), rng.integers(0, w)] += rng.random(3).astype(np.float32) * 40
+    return img
+
+
+def test_envmap_functions_vs_oracle(renderer, O):
+    img = _envmap(64)
+    q = np.array([0.2, -0.1, 0.3, 0.9], np.float32)
+    rng = np.random.default_rng(11)
+    n = 8192
+    u = rng.random((n, 2)).astype(np.float32)
+    wi = rng.normal(size=(n, 3)).astype(np.float32)
+    wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    _load_cornell(renderer, O, 64, 64)
+    renderer.upload_envmap(img, q)
+    try:
+        g = renderer.test_envmap(u, wi)
+    finally:
+        renderer.clear_envmap()
+    a = O.envmap_sample(img, q, u)
+    e = O.envmap_eval(img, q, wi)
+    # the two binary searches and the table reads are exact: uv, pdf, texel bit-identical
+    assert np.array_equal(g["ok"], a["ok"])
+    assert np.array_equal(g["uv"], a["uv"])
+    assert np.allclose(g["pdf"], a["pdf"], rtol=2e-6, atol=0)        # one v_rcp-based division
+    assert np.array_equal(g["Le"], a["Le"])
+    assert np.abs(g["wi"] - a["wi"]).max() < 2e-6                     # sinf/cosf + quaternion with FMA contraction
+    # evaluation by direction: the texel can flip for directions within rounding of a texel border
+    same = (g["Le_dir"] == e["Le"]).all(axis=1)
+    assert same.mean() > 0.999
+    assert np.allclose(g["pdf_dir"][same], e["pdf"][same], rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+def test_envmap_film_vs_oracle(renderer, pkg, O, accel):
+    """Open random-triangle scene (most rays leave it, so both env-map code paths -- seen by a path ray with MIS,
+    sampled by NEE -- carry most of the image), brute force and BVH kernels."""
+    scene = pkg.host_scene.random_triangle_scene(300, width=48, height=40)
+    img = _envmap(32, seed=3)
+    osc = O.Scene(scene.xs, scene.ys, scene.zs, scene.mat_id, scene.bsdfs, scene.lights, scene.inf_lights, scene.camera)
+    osc.set_envmap(img, (0.1, 0.2, -0.3, 0.9))
+    renderer.upload_scene(osc)
+    renderer.set_limits(6)
+    renderer.set_accel(accel)
+    renderer.set_partition(0, 1)
+    try:
+        renderer.film_clear()
+        renderer.render(32)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
+    finally:
+        renderer.set_accel(0)
+        renderer.clear_envmap()
+    om, om2 = O.render(osc, 32, max_depth=6, threads=8)[:2]
+    assert np.array_equal(m2[..., 3], om2[..., 3])
+    assert om[..., :3].max() > 0.5                      # the map is bright: this is not a black image
+    rmse = float(np.sqrt(np.mean((mean[..., :3] - om[..., :3]) ** 2)))
+    rel = rmse / float(om[..., :3].mean())
+    assert rel < 2e-3, (rmse, rel)                      # hot texels (x40) make absolute RMSE scale with the map
+
+
+def test_envmap_clear_restores_constant_environment(renderer, O):
+    _load_cornell(renderer, O, 48, 48, 8)
+    renderer.render(8); renderer.sync()
+    base = renderer.download_film()
+    renderer.upload_envmap(_envmap(16))
+    renderer.film_clear(); renderer.render(8); renderer.sync()
+    withmap = renderer.download_film()
+    renderer.clear_envmap()
+    renderer.film_clear(); renderer.render(8); renderer.sync()
+    again = renderer.download_film()
+    assert np.array_equal(base[0], again[0]) and np.array_equal(base[1], again[1])
+    assert not np.array_equal(base[0], withmap[0])
