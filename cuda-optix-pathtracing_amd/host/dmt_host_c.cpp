@@ -22,6 +22,31 @@ dmt_host_scene* dmt_host_scene_random_triangles(uint64_t count, uint64_t seed) {
   if (h) h->s = randomTriangleScene(size_t(count), seed);
   return h;
 }
+// JSON front-end; on failure returns null and copies the message (NUL-terminated, truncated) into err
+dmt_host_scene* dmt_host_scene_load_json(const char* path, int* max_depth, int* samples_per_pixel, char* err, uint64_t err_cap) {
+  auto* h = new (std::nothrow) dmt_host_scene();
+  if (!h || !path) return delete h, nullptr;
+  JsonScene js;
+  std::string msg;
+  if (!loadJsonScene(path, js, &msg)) {
+    if (err && err_cap) {
+      size_t const n = msg.size() < err_cap - 1 ? msg.size() : size_t(err_cap - 1);
+      memcpy(err, msg.data(), n);
+      err[n] = 0;
+    }
+    delete h;
+    return nullptr;
+  }
+  h->s = std::move(js.scene);
+  if (max_depth) *max_depth = js.maxDepth;
+  if (samples_per_pixel) *samples_per_pixel = js.samplesPerPixel;
+  return h;
+}
+const float* dmt_host_scene_env_rgb(const dmt_host_scene* h, int* width, int* height) {
+  if (width) *width = h->s.envWidth;
+  if (height) *height = h->s.envHeight;
+  return h->s.envRgb.empty() ? nullptr : h->s.envRgb.data();
+}
 void dmt_host_scene_destroy(dmt_host_scene* h) { delete h; }
 
 uint64_t dmt_host_scene_triangle_count(const dmt_host_scene* h) { return h->s.triangleCount(); }

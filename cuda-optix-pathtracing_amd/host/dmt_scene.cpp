@@ -395,7 +395,10 @@ int uploadScene(dmt_ctx* ctx, Scene const& s) {
   rc = dmt_upload_lights(ctx, s.lights.data(), uint32_t(s.lights.size()), s.infiniteLights.data(),
                          uint32_t(s.infiniteLights.size()));
   if (rc) return rc;
-  return dmt_set_camera(ctx, &s.camera);
+  rc = dmt_set_camera(ctx, &s.camera);
+  if (rc) return rc;
+  if (!s.envRgb.empty()) return dmt_upload_envmap(ctx, s.envRgb.data(), s.envWidth, s.envHeight, s.envQuat, s.envScale);
+  return dmt_clear_envmap(ctx);
 }
 
 }  // namespace dmt_host

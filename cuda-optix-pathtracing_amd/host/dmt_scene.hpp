@@ -59,6 +59,11 @@ struct Scene {
   std::vector<uint32_t> matId;
   std::vector<Packed32> bsdfs, lights, infiniteLights;
   dmt_camera camera{};
+  // optional env-map light (A18; the JSON front-end's "envlight"): RGB floats, envHeight x envWidth x 3
+  std::vector<float> envRgb;
+  int envWidth = 0, envHeight = 0;
+  float envQuat[4] = {0.f, 0.f, 0.f, 1.f};  // lightFromRender, x y z w
+  float envScale = 1.f;
 
   size_t triangleCount() const { return matId.size(); }
   // addModel + the material walk of triSoupFromTriangles: the FIRST mesh always gets material 0
@@ -76,6 +81,20 @@ Scene cornellBox();
 // (splitmix64 seed 0x5EED1234, centroids in [-10,10]^3 shifted to y in [5,25], edges in
 // [-0.15,0.15]^3, material = index mod 7 over the Cornell BSDFs, spot light at (0,15,12), env 0.1)
 Scene randomTriangleScene(size_t triangleCount, uint64_t seed = 0x5EED1234ull);
+
+// JSON scene front-end: the reference's scene description (src/core/private/core-parser.cpp:256-1455;
+// keys camera / film / textures / materials / objects / lights / envlight / transforms / world) flattened to the
+// megakernel's upload arrays.  Returns false and a message for anything the reference's parser rejects, and for
+// what this path cannot represent yet (image textures, normal maps, FBX objects).
+struct JsonScene {
+  Scene scene;
+  int maxDepth = 5;          // camera "max-depth" (core-types.h:30)
+  int samplesPerPixel = 1;   // film "samples"   (core-types.h:28)
+};
+bool loadJsonScene(std::string const& path, JsonScene& out, std::string* error = nullptr);
+// 8-bit grey / RGB / RGBA non-interlaced PNG -> RGB floats, byte / 255 as the reference's loadImageAsRGB
+// (core-parser.cpp:156-167)
+bool readPngRgb(std::string const& path, std::vector<float>& rgb, int& width, int& height, std::string* error = nullptr);
 
 // 8-bit images of the film, exactly as the reference's writers quantise them
 // (CC/private/host_utils.cu:475-497): u8 = (uint8)min(max(v,0)*255, 255), linear, truncating;

@@ -1,7 +1,7 @@
 // dmt-megakernel-hip -- command-line driver with the reference's dmt-megakernel surface
 // (examples/triangles/megakernel/main.cu:67-243; flags CC/private/host_utils.cu:39-92):
 //   --width <N> --height <N> --spp <N> --kspp <N> --log-level info|verbose --save-partial
-// plus --max-depth <N> (reference constant 32), --device <ordinal>, --out <dir>.
+// plus --max-depth <N> (reference constant 32), --device <ordinal>, --out <dir>, --scene <file.json>, --bvh.
 // Renders the hard-coded cornellBox() scene kspp samples per launch and writes
 // output-<spp>.png and output-<spp>_sqrt_mse.png next to the executable (or into --out).
 #include <unistd.h>
@@ -22,6 +22,9 @@ struct Config {  // defaults: CC/public/cuda-core/host_utils.cuh:25-31
   int maxDepth = 32, device = 0;
   std::string logLevel = "info", outDir;
   bool savePartial = false;
+  std::string scenePath;  // --scene <file.json>: the reference's JSON scene description instead of cornellBox()
+  bool bvh = false;       // --bvh: traverse the 4-wide BVH instead of testing every triangle
+  bool widthSet = false, heightSet = false, sppSet = false, depthSet = false;
 
   std::string validate() const {  // host_utils.cuh:35-62
     if (width <= 0) return "invalid width: should be bigger than zero. got " + std::to_string(width);
@@ -46,7 +49,10 @@ void printHelp() {
       "  --save-partial    -- Whether to save images every <kspp> samples\n"
       "  --max-depth <N>   -- Bounce cap (reference: 32)\n"
       "  --device <N>      -- GPU ordinal\n"
-      "  --out <dir>       -- Output directory (default: the executable's directory)");
+      "  --out <dir>       -- Output directory (default: the executable's directory)\n"
+      "  --scene <file>    -- JSON scene (camera/film/materials/objects/lights/envlight/transforms/world);\n"
+      "                       its resolution, samples and max-depth apply unless given on the command line\n"
+      "  --bvh             -- BVH traversal instead of the brute-force triangle loop");
 }
 
 Config parseArguments(int argc, char** argv) {
@@ -54,13 +60,15 @@ Config parseArguments(int argc, char** argv) {
   for (int i = 1; i < argc; ++i) {
     std::string const a = argv[i];
     bool const more = i + 1 < argc;
-    if (a == "--width" && more) c.width = std::atoi(argv[++i]);
-    else if (a == "--height" && more) c.height = std::atoi(argv[++i]);
-    else if (a == "--spp" && more) c.spp = std::atoi(argv[++i]);
+    if (a == "--width" && more) c.width = std::atoi(argv[++i]), c.widthSet = true;
+    else if (a == "--height" && more) c.height = std::atoi(argv[++i]), c.heightSet = true;
+    else if (a == "--spp" && more) c.spp = std::atoi(argv[++i]), c.sppSet = true;
+    else if (a == "--scene" && more) c.scenePath = argv[++i];
+    else if (a == "--bvh") c.bvh = true;
     else if (a == "--kspp" && more) c.kspp = std::atoi(argv[++i]);
     else if (a == "--log-level" && more) c.logLevel = argv[++i];
     else if (a == "--save-partial") c.savePartial = true;
-    else if (a == "--max-depth" && more) c.maxDepth = std::atoi(argv[++i]);
+    else if (a == "--max-depth" && more) c.maxDepth = std::atoi(argv[++i]), c.depthSet = true;
     else if (a == "--device" && more) c.device = std::atoi(argv[++i]);
     else if (a == "--out" && more) c.outDir = argv[++i];
     else if (a == "--help") { printHelp(); std::exit(0); }
@@ -87,7 +95,20 @@ int fail(dmt_ctx* ctx, char const* what) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  Config const cfg = parseArguments(argc, argv);
+  Config cfg = parseArguments(argc, argv);
+  dmt_host::JsonScene json;
+  if (!cfg.scenePath.empty()) {
+    std::string err;
+    if (!dmt_host::loadJsonScene(cfg.scenePath, json, &err)) {
+      std::fprintf(stderr, "scene '%s': %s\n", cfg.scenePath.c_str(), err.c_str());
+      return 1;
+    }
+    if (!cfg.widthSet) cfg.width = json.scene.camera.width;
+    if (!cfg.heightSet) cfg.height = json.scene.camera.height;
+    if (!cfg.sppSet) cfg.spp = json.samplesPerPixel;
+    if (!cfg.depthSet) cfg.maxDepth = json.maxDepth;
+    if (cfg.kspp > cfg.spp) cfg.kspp = cfg.spp;
+  }
   if (std::string const err = cfg.validate(); !err.empty()) {
     std::fprintf(stderr, "%s\n", err.c_str());
     printHelp();
@@ -99,10 +120,11 @@ int main(int argc, char** argv) {
 
   dmt_ctx* ctx = nullptr;
   if (dmt_ctx_create(cfg.device, &ctx) != DMT_OK) return fail(nullptr, "dmt_ctx_create");
-  dmt_host::Scene scene = dmt_host::cornellBox();
+  dmt_host::Scene scene = cfg.scenePath.empty() ? dmt_host::cornellBox() : std::move(json.scene);
   scene.camera.width = cfg.width, scene.camera.height = cfg.height, scene.camera.spp = cfg.kspp;
   if (dmt_host::uploadScene(ctx, scene) != DMT_OK) return fail(ctx, "uploadScene");
   if (dmt_set_limits(ctx, cfg.maxDepth) != DMT_OK) return fail(ctx, "dmt_set_limits");
+  if (cfg.bvh && dmt_set_accel(ctx, DMT_ACCEL_BVH) != DMT_OK) return fail(ctx, "dmt_set_accel");
 
   std::string const dir = cfg.outDir.empty() ? executableDirectory() : cfg.outDir;
   size_t const pixels = size_t(cfg.width) * size_t(cfg.height);

@@ -18,7 +18,8 @@ def load_host_library():
         lib = C.CDLL(str(so))
         for name in ("dmt_host_scene_cornell_box", "dmt_host_scene_random_triangles", "dmt_host_scene_xs",
                      "dmt_host_scene_ys", "dmt_host_scene_zs", "dmt_host_scene_mat_ids", "dmt_host_scene_bsdfs",
-                     "dmt_host_scene_lights", "dmt_host_scene_infinite_lights", "dmt_host_scene_camera"):
+                     "dmt_host_scene_lights", "dmt_host_scene_infinite_lights", "dmt_host_scene_camera",
+                     "dmt_host_scene_load_json", "dmt_host_scene_env_rgb"):
             getattr(lib, name).restype = C.c_void_p
         lib.dmt_host_scene_random_triangles.argtypes = [C.c_uint64, C.c_uint64]
         lib.dmt_host_scene_triangle_count.restype = C.c_uint64
@@ -56,6 +57,11 @@ class HostScene:
         self.inf_lights = _copy(L.dmt_host_scene_infinite_lights(h), np.uint8,
                                 32 * L.dmt_host_scene_infinite_light_count(h)).reshape(-1, 32)
         self.camera = _copy(L.dmt_host_scene_camera(h), np.uint8, 44)
+        ew, eh = C.c_int(), C.c_int()
+        env = L.dmt_host_scene_env_rgb(h, C.byref(ew), C.byref(eh))
+        self.env_rgb = _copy(env, np.float32, 3 * ew.value * eh.value).reshape(eh.value, ew.value, 3) if env else None
+        self.env_quat, self.env_scale = np.array([0, 0, 0, 1], np.float32), 1.0
+        self.max_depth, self.spp = None, None
         L.dmt_host_scene_destroy(h)
 
     @property
@@ -73,6 +79,20 @@ class HostScene:
     def set_resolution(self, w, h):
         self.camera[24:32] = np.array([w, h], np.int32).view(np.uint8)
         return self
+
+
+def load_json(path):
+    """The reference's JSON scene description (core-parser.cpp) -> HostScene (+ .max_depth, .spp, .env_rgb).
+    Raises ValueError with the loader's message when the file is rejected."""
+    L = load_host_library()
+    md, spp = C.c_int(), C.c_int()
+    err = C.create_string_buffer(1024)
+    h = L.dmt_host_scene_load_json(str(path).encode(), C.byref(md), C.byref(spp), err, C.c_uint64(len(err)))
+    if not h:
+        raise ValueError(err.value.decode() or "dmt_host_scene_load_json failed")
+    s = HostScene(h)
+    s.max_depth, s.spp = md.value, spp.value
+    return s
 
 
 def cornell_box(width=None, height=None):

@@ -1,0 +1,114 @@
+"""JSON scene front-end: host C++ loader (host/dmt_json_scene.cpp) vs the independent numpy restatement
+of the reference's parser semantics (oracle/json_scene_ref.py), plus the rejection rules of core-parser.cpp.
+The fixture scene is this repo's own file in the reference's schema (tests/golden/json_scene/).  No GPU needed."""
+import json
+import shutil
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "oracle"))
+import json_scene_ref  # noqa: E402
+
+SCENE = GOLDEN / "json_scene" / "three_boxes.json"
+
+
+def test_loader_matches_restatement(pkg, O):
+    got = pkg.host_scene.load_json(SCENE)
+    ref = json_scene_ref.load(SCENE, O)
+    assert got.tri_count == 26 and np.array_equal(got.mat_id, ref["mat_id"])
+    # world members are visited in key order: ground (plane, chalk), left (cube, glass), right (cube, gold)
+    assert got.mat_id.tolist() == [2] * 2 + [0] * 12 + [1] * 12
+    for k in ("xs", "ys", "zs"):
+        # transforms are float32 products in glm's order on both sides; cosf/sinf may differ in the last ulp
+        assert np.abs(getattr(got, k) - ref[k]).max() < 2e-6, k
+    assert np.array_equal(got.bsdfs, ref["bsdfs"])            # packed records: byte-identical
+    assert got.lights.shape == (2, 32) and got.inf_lights.shape[0] == 0
+    assert np.array_equal(got.lights, ref["lights"])
+    cam = got.camera
+    f = cam[:24].view(np.float32)
+    assert np.array_equal(f[:3], ref["camera"]["dir"]) and np.array_equal(f[3:6], ref["camera"]["pos"])
+    assert (got.width, got.height) == (96, 64) and cam[32:36].view(np.int32)[0] == 8
+    assert cam[36:44].view(np.float32).tolist() == [24.0, 36.0]
+    assert (got.max_depth, got.spp) == (6, 8)
+
+
+def test_envlight_png_is_loaded_as_bytes_over_255(pkg):
+    got = pkg.host_scene.load_json(SCENE)
+    assert got.env_rgb.shape == (16, 32, 3)
+    # the fixture PNG was written with rows 40 + 8 y / 60 + 4 x / 120 and three white texels
+    y, x = 5, 9
+    assert got.env_rgb[y, x].tolist() == [np.float32((40 + 8 * y) / 255.0), np.float32((60 + 4 * x) / 255.0),
+                                          np.float32(120 / 255.0)]
+    assert (got.env_rgb == 1.0).all(axis=2).sum() == 3
+
+
+def _variant(tmp_path, edit):
+    d = json.loads(SCENE.read_text())
+    edit(d)
+    shutil.copy(SCENE.parent / "sky_32x16.png", tmp_path / "sky_32x16.png")
+    p = tmp_path / "scene.json"
+    p.write_text(json.dumps(d))
+    return p
+
+
+@pytest.mark.parametrize("edit, needle", [
+    (lambda d: d.pop("lights"), "lacking some keys"),                                        # core-parser.cpp:1371
+    (lambda d: d.update(extra=1), "extraneous key"),
+    (lambda d: d["camera"].update(position=[0, 0, 0]), "at most 4 members"),                 # :741 (5 members)
+    (lambda d: d["film"].update(samples=0), "positive integer"),                             # :290-294
+    (lambda d: d["film"].update(samples=2.5), "positive integer"),
+    (lambda d: d["materials"][0].pop("roughness"), "should specify a 'roughness'"),          # :480-486
+    (lambda d: d["materials"][0].update(shiny=True), "extraneous key 'shiny'"),              # :446-459
+    (lambda d: d["materials"][1].update(eta=[1, 1, 1]), "both 'eta' and 'etak'"),            # :600
+    (lambda d: d["materials"][0].update({"oren-nayar-dielectric": None}), "only one of"),    # :665
+    (lambda d: d["materials"].append(dict(d["materials"][0])), "Duplicate material name"),   # :421
+    (lambda d: d["materials"][0].update(diffuse="paint"), "existing named texture"),         # :497
+    (lambda d: d["objects"][0].update(material="nope"), "unknown material"),
+    (lambda d: d["objects"][0].update(shape="torus"), "unrecognized shape"),
+    (lambda d: d["objects"][0].update(type="FBX", path="x.fbx") or d["objects"][0].pop("shape"), "FBX"),
+    (lambda d: d["lights"][0].update(radius=1), "extraneous key 'radius'"),                  # :1001-1012
+    (lambda d: d["lights"][1].update(type="area"), "unrecognized type"),
+    (lambda d: d["transforms"][0].update(name=""), "non-empty 'name'"),                      # :836
+    (lambda d: d["world"]["room"]["left"].update(instances=["ghost"]), "unknown object"),
+    (lambda d: d.update(envlight="missing.png"), "envlight"),
+])
+def test_rejections(pkg, tmp_path, edit, needle):
+    with pytest.raises(ValueError) as e:
+        pkg.host_scene.load_json(_variant(tmp_path, edit))
+    assert needle in str(e.value), str(e.value)
+
+
+def test_defaults_and_clamps(pkg, O, tmp_path):
+    """cone-angle clamps to [10, 120], falloff to [1, 80] (core-parser.cpp:1040-1052); lights default to intensity 1;
+    a transform without srt is the identity; max-depth defaults to 5, samples to 1 (core-types.h:28-30)."""
+    def edit(d):
+        d["camera"].pop("max-depth")
+        d["film"].pop("samples")
+        d["lights"][0].update({"cone-angle": 500, "falloff-percentage": 0.01})
+        d["lights"][0].pop("radiant-intensity")
+        d["transforms"].append({"name": "id"})
+        d["world"]["id"] = {"lights": ["bulb"]}
+    p = _variant(tmp_path, edit)
+    got, ref = pkg.host_scene.load_json(p), json_scene_ref.load(p, O)
+    assert (got.max_depth, got.spp) == (5, 1)
+    assert got.lights.shape[0] == 3 and np.array_equal(got.lights, ref["lights"])
+
+
+def test_json_reader_details(pkg, tmp_path):
+    """escapes, exponents, nested empties; a repeated key keeps the last value (nlohmann's behaviour)."""
+    text = SCENE.read_text().replace('"samples": 8', '"samples": 8, "samples": 3').replace('"resolutionX": 96', '"resolutionX": 9.6e1')
+    text = text.replace('"name": "bulb"', '"name": "b\\u0075lb"')
+    shutil.copy(SCENE.parent / "sky_32x16.png", tmp_path / "sky_32x16.png")
+    p = tmp_path / "s.json"
+    p.write_text(text)
+    got = pkg.host_scene.load_json(p)
+    assert got.spp == 3 and got.width == 96 and got.lights.shape[0] == 2
+    (tmp_path / "bad.json").write_text(text[:-3])
+    with pytest.raises(ValueError):
+        pkg.host_scene.load_json(tmp_path / "bad.json")
