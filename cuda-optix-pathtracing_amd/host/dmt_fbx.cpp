@@ -1,0 +1,250 @@
+// dmt_fbx.cpp -- binary FBX mesh reader, replacing the FBX SDK call of the reference's
+// MeshFbxParser::ImportFBX (src/core/private/core-mesh-parser.cpp:617-687; declared
+// src/core/public/core-mesh-parser.h:15-24), which this image does not have.
+//
+// Reads what that function uses: the FIRST mesh geometry of the file (Objects/Geometry "Mesh": Vertices,
+// PolygonVertexIndex), triangulated as fans, with the local transform of the Model it is connected to
+// (Properties70: Lcl Translation / Lcl Rotation (Euler XYZ, degrees) / Lcl Scaling) and the file's unit scale
+// brought to centimetres (GlobalSettings/UnitScaleFactor), as ImportFBX does with FbxSystemUnit::cm.ConvertScene.
+// File format (Kaydara binary, versions 7100-7400: 32-bit record offsets; 7500+: 64-bit): 27-byte header, then
+// nested node records {end offset, property count, property bytes, name, properties, children, 13/25-byte null
+// record}; array properties (f d l i b) may be zlib-deflated.
+// NOT reproduced: the SDK's axis-system conversion (ImportFBX asks for Z-up / parity-odd / LEFT-handed; Blender
+// writes Z-up right-handed files, and what the SDK does to the geometry in that case cannot be checked here),
+// pre/post rotations, pivots, geometric transforms, instancing, animation.  Parity unpinned: no FBX SDK, no
+// reference-side vectors; tested against files written by this repo's own writer (tools/make_fbx_fixture.py)
+// and against the structure of the reference's scenes/sphere.fbx where that file is present.
+#include <zlib.h>
+
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "dmt_scene.hpp"
+
+namespace dmt_host {
+namespace {
+
+struct Prop {
+  char type = 0;
+  double num = 0;             // scalar types
+  std::string str;            // S / R
+  std::vector<double> arr;    // array types, widened
+};
+struct Node {
+  std::string name;
+  std::vector<Prop> props;
+  std::vector<Node> children;
+  Node const* child(char const* n) const {
+    for (auto const& c : children)
+      if (c.name == n) return &c;
+    return nullptr;
+  }
+};
+
+struct Reader {
+  std::vector<unsigned char> d;
+  bool wide = false;  // 64-bit offsets (version >= 7500)
+  std::string err;
+
+  template <class T>
+  bool get(size_t o, T& v) {
+    if (o + sizeof(T) > d.size()) return err = "truncated file", false;
+    memcpy(&v, &d[o], sizeof(T));
+    return true;
+  }
+  bool readProps(size_t& o, uint64_t count, std::vector<Prop>& out) {
+    for (uint64_t i = 0; i < count; ++i) {
+      if (o >= d.size()) return err = "truncated properties", false;
+      Prop p;
+      p.type = char(d[o++]);
+      switch (p.type) {
+        case 'Y': { int16_t v; if (!get(o, v)) return false; p.num = v, o += 2; break; }
+        case 'C': { if (o >= d.size()) return err = "truncated", false; p.num = d[o], o += 1; break; }
+        case 'I': { int32_t v; if (!get(o, v)) return false; p.num = v, o += 4; break; }
+        case 'F': { float v; if (!get(o, v)) return false; p.num = v, o += 4; break; }
+        case 'D': { double v; if (!get(o, v)) return false; p.num = v, o += 8; break; }
+        case 'L': { int64_t v; if (!get(o, v)) return false; p.num = double(v), o += 8; break; }
+        case 'S': case 'R': {
+          uint32_t len;
+          if (!get(o, len)) return false;
+          o += 4;
+          if (o + len > d.size()) return err = "truncated string", false;
+          p.str.assign(reinterpret_cast<char const*>(&d[o]), len);
+          o += len;
+          break;
+        }
+        case 'f': case 'd': case 'l': case 'i': case 'b': {
+          uint32_t n, enc, clen;
+          if (!get(o, n) || !get(o + 4, enc) || !get(o + 8, clen)) return false;
+          o += 12;
+          if (o + clen > d.size()) return err = "truncated array", false;
+          size_t const esz = p.type == 'f' || p.type == 'i' ? 4 : (p.type == 'b' ? 1 : 8);
+          std::vector<unsigned char> raw(size_t(n) * esz);
+          if (enc == 1) {
+            uLongf len = uLongf(raw.size());
+            if (uncompress(raw.data(), &len, &d[o], clen) != Z_OK || len != raw.size()) return err = "bad deflate stream in array", false;
+          } else {
+            if (clen != raw.size()) return err = "array length mismatch", false;
+            memcpy(raw.data(), &d[o], raw.size());
+          }
+          o += clen;
+          p.arr.resize(n);
+          for (uint32_t k = 0; k < n; ++k) {
+            unsigned char const* q = &raw[size_t(k) * esz];
+            if (p.type == 'f') { float v; memcpy(&v, q, 4); p.arr[k] = v; }
+            else if (p.type == 'd') { double v; memcpy(&v, q, 8); p.arr[k] = v; }
+            else if (p.type == 'i') { int32_t v; memcpy(&v, q, 4); p.arr[k] = v; }
+            else if (p.type == 'l') { int64_t v; memcpy(&v, q, 8); p.arr[k] = double(v); }
+            else p.arr[k] = q[0];
+          }
+          break;
+        }
+        default: return err = std::string("unknown property type '") + p.type + "'", false;
+      }
+      out.push_back(std::move(p));
+    }
+    return true;
+  }
+  // returns 0 on the null record, else the end offset; fills `n`
+  bool readNode(size_t o, Node& n, size_t& end, int depth) {
+    if (depth > 64) return err = "nesting too deep", false;
+    uint64_t e = 0, np = 0, pl = 0;
+    size_t hdr;
+    if (wide) {
+      uint64_t a, b, c;
+      if (!get(o, a) || !get(o + 8, b) || !get(o + 16, c)) return false;
+      e = a, np = b, pl = c, hdr = 24;
+    } else {
+      uint32_t a, b, c;
+      if (!get(o, a) || !get(o + 4, b) || !get(o + 8, c)) return false;
+      e = a, np = b, pl = c, hdr = 12;
+    }
+    if (e == 0) return end = 0, true;
+    if (e > d.size() || e <= o) return err = "bad record end offset", false;
+    uint8_t nl;
+    if (!get(o + hdr, nl)) return false;
+    size_t p = o + hdr + 1;
+    if (p + nl > d.size()) return err = "truncated name", false;
+    n.name.assign(reinterpret_cast<char const*>(&d[p]), nl);
+    p += nl;
+    size_t const propsEnd = p + size_t(pl);
+    if (propsEnd > e) return err = "property list overruns record", false;
+    if (!readProps(p, np, n.props)) return false;
+    p = propsEnd;
+    while (p < e) {
+      Node c;
+      size_t ce = 0;
+      if (!readNode(p, c, ce, depth + 1)) return false;
+      if (ce == 0) break;  // null record
+      n.children.push_back(std::move(c));
+      p = ce;
+    }
+    end = size_t(e);
+    return true;
+  }
+};
+
+// Properties70/P "name": numeric values after the four descriptor strings
+bool prop70(Node const& owner, char const* name, double* out, int n) {
+  Node const* p70 = owner.child("Properties70");
+  if (!p70) return false;
+  for (auto const& P : p70->children) {
+    if (P.name != "P" || P.props.empty() || P.props[0].str != name) continue;
+    if (int(P.props.size()) < 4 + n) return false;
+    for (int i = 0; i < n; ++i) out[i] = P.props[size_t(4 + i)].num;
+    return true;
+  }
+  return false;
+}
+
+}  // namespace
+
+bool readFbxMesh(std::string const& path, std::vector<Triangle>& out, std::string* error) {
+  auto bad = [&](std::string const& m) {
+    if (error) *error = path + ": " + m;
+    return false;
+  };
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return bad("cannot open");
+  Reader r;
+  r.d.assign((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  static char const magic[] = "Kaydara FBX Binary  ";
+  if (r.d.size() < 27 || memcmp(r.d.data(), magic, 20) != 0) return bad("not a binary FBX file (ASCII FBX is not supported)");
+  uint32_t version;
+  memcpy(&version, &r.d[23], 4);
+  r.wide = version >= 7500;
+  Node root;
+  for (size_t o = 27; o + (r.wide ? 25 : 13) <= r.d.size();) {
+    Node n;
+    size_t end = 0;
+    if (!r.readNode(o, n, end, 0)) return bad(r.err);
+    if (end == 0) break;
+    root.children.push_back(std::move(n));
+    o = end;
+  }
+  Node const* objects = root.child("Objects");
+  if (!objects) return bad("no Objects section");
+  Node const* geom = nullptr;
+  for (auto const& c : objects->children)
+    if (c.name == "Geometry" && c.props.size() >= 3 && c.props[2].str == "Mesh" && c.child("Vertices") && c.child("PolygonVertexIndex")) {
+      geom = &c;
+      break;  // "Only first mesh of this FBX file will be read" (core-mesh-parser.cpp:661-666)
+    }
+  if (!geom) return bad("No meshes to import");
+  std::vector<double> const& V = geom->child("Vertices")->props.empty() ? std::vector<double>() : geom->child("Vertices")->props[0].arr;
+  std::vector<double> const& I = geom->child("PolygonVertexIndex")->props.empty() ? std::vector<double>() : geom->child("PolygonVertexIndex")->props[0].arr;
+  if (V.empty() || V.size() % 3 || I.empty()) return bad("empty or malformed mesh arrays");
+
+  // the Model this geometry is connected to (Connections: C "OO" child parent)
+  double T[3] = {0, 0, 0}, R[3] = {0, 0, 0}, S[3] = {1, 1, 1};
+  {
+    int64_t const gid = geom->props.empty() ? 0 : int64_t(geom->props[0].num);
+    int64_t modelId = 0;
+    if (Node const* con = root.child("Connections"))
+      for (auto const& c : con->children)
+        if (c.name == "C" && c.props.size() >= 3 && c.props[0].str == "OO" && int64_t(c.props[1].num) == gid) modelId = int64_t(c.props[2].num);
+    for (auto const& c : objects->children)
+      if (c.name == "Model" && !c.props.empty() && int64_t(c.props[0].num) == modelId && modelId != 0) {
+        prop70(c, "Lcl Translation", T, 3);
+        prop70(c, "Lcl Rotation", R, 3);
+        prop70(c, "Lcl Scaling", S, 3);
+      }
+  }
+  double unit = 1.0;  // centimetres per file unit
+  if (Node const* gs = root.child("GlobalSettings")) prop70(*gs, "UnitScaleFactor", &unit, 1);
+  // M = T * Rz * Ry * Rx * S (FBX eEulerXYZ: X applied first), then the unit scale
+  double const kDeg = 3.14159265358979323846 / 180.0;
+  double const cx = std::cos(R[0] * kDeg), sx = std::sin(R[0] * kDeg), cy = std::cos(R[1] * kDeg), sy = std::sin(R[1] * kDeg);
+  double const cz = std::cos(R[2] * kDeg), sz = std::sin(R[2] * kDeg);
+  double const M[3][3] = {{cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx},
+                          {sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx},
+                          {-sy, cy * sx, cy * cx}};
+  size_t const nv = V.size() / 3;
+  std::vector<Vec3> P(nv);
+  for (size_t i = 0; i < nv; ++i) {
+    double const x = V[3 * i] * S[0], y = V[3 * i + 1] * S[1], z = V[3 * i + 2] * S[2];
+    P[i] = Vec3{float((M[0][0] * x + M[0][1] * y + M[0][2] * z + T[0]) * unit), float((M[1][0] * x + M[1][1] * y + M[1][2] * z + T[1]) * unit),
+                float((M[2][0] * x + M[2][1] * y + M[2][2] * z + T[2]) * unit)};
+  }
+  out.clear();
+  std::vector<uint32_t> poly;
+  for (double di : I) {
+    int64_t idx = int64_t(di);
+    bool const last = idx < 0;
+    if (last) idx = ~idx;  // the last index of a polygon is stored as its bitwise complement
+    if (idx < 0 || size_t(idx) >= nv) return bad("vertex index out of range");
+    poly.push_back(uint32_t(idx));
+    if (last) {
+      for (size_t k = 1; k + 1 < poly.size(); ++k) out.push_back(Triangle{P[poly[0]], P[poly[k]], P[poly[k + 1]]});
+      poly.clear();
+    }
+  }
+  if (out.empty()) return bad("mesh has no polygons");
+  return true;
+}
+
+}  // namespace dmt_host

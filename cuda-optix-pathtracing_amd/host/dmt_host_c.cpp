@@ -42,6 +42,26 @@ dmt_host_scene* dmt_host_scene_load_json(const char* path, int* max_depth, int* 
   if (samples_per_pixel) *samples_per_pixel = js.samplesPerPixel;
   return h;
 }
+// first mesh of a binary FBX file as a triangle list (9 floats per triangle); returns the triangle count, -1 on
+// failure (message in err).  Call with out == null to get the count.
+int64_t dmt_host_read_fbx(const char* path, float* out9, uint64_t cap_triangles, char* err, uint64_t err_cap) {
+  std::vector<Triangle> tris;
+  std::string msg;
+  if (!path || !readFbxMesh(path, tris, &msg)) {
+    if (err && err_cap) {
+      size_t const n = msg.size() < err_cap - 1 ? msg.size() : size_t(err_cap - 1);
+      memcpy(err, msg.data(), n);
+      err[n] = 0;
+    }
+    return -1;
+  }
+  if (out9)
+    for (size_t i = 0; i < tris.size() && i < cap_triangles; ++i) {
+      Vec3 const v[3] = {tris[i].v0, tris[i].v1, tris[i].v2};
+      for (int k = 0; k < 3; ++k) out9[9 * i + 3 * size_t(k)] = v[k].x, out9[9 * i + 3 * size_t(k) + 1] = v[k].y, out9[9 * i + 3 * size_t(k) + 2] = v[k].z;
+    }
+  return int64_t(tris.size());
+}
 const float* dmt_host_scene_env_rgb(const dmt_host_scene* h, int* width, int* height) {
   if (width) *width = h->s.envWidth;
   if (height) *height = h->s.envHeight;

@@ -17,8 +17,8 @@
 // flat scene, so three mappings are this build's own and are documented in DESIGN.md: materials become ONE packed
 // BSDF record each ("oren-nayar-dielectric" -> Oren-Nayar; else metallic < 0.5 -> GGX dielectric, >= 0.5 -> GGX
 // conductor, alpha_y = roughness, alpha_x = anisotropy * roughness as core-material.cpp:262-263), instances are
-// flattened (every vertex transformed on the host), and textures / FBX objects are rejected with a clear error
-// (no texture unit or FBX reader on this path yet).
+// flattened (every vertex transformed on the host), and image textures / normal maps are rejected with a clear error
+// (no texture unit on this path yet).  FBX objects go through this build's own binary reader (dmt_fbx.cpp).
 #include <zlib.h>
 
 #include <cmath>
@@ -85,6 +85,11 @@ Vec3 xformPoint(Mat4 const& M, Vec3 p) {  // M * (p, 1)
 Vec3 xformVector(Mat4 const& M, Vec3 v) {
   return Vec3{M.m[0] * v.x + M.m[4] * v.y + M.m[8] * v.z, M.m[1] * v.x + M.m[5] * v.y + M.m[9] * v.z,
               M.m[2] * v.x + M.m[6] * v.y + M.m[10] * v.z};
+}
+
+std::string directoryOf(std::string const& path) {
+  size_t const p = path.find_last_of('/');
+  return p == std::string::npos ? std::string(".") : path.substr(0, p);
 }
 
 float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -284,7 +289,7 @@ void parseMaterial(Value const& m, State& st) {
   st.materialList.push_back(mat);
 }
 
-void parseObject(Value const& o, State& st) {
+void parseObject(Value const& o, State& st, std::string const& baseDir) {
   if (!o.isObject()) fail("The 'objects' array should contain only objects");
   if (!o.contains("name") || !o.at("name").isString()) fail("object should have a 'name' string");
   std::string const name = o.at("name").string;
@@ -297,7 +302,9 @@ void parseObject(Value const& o, State& st) {
   mesh.material = st.materials.at(o.at("material").string);
   if (type == "fbx" || type == "FBX") {
     onlyKeys(o, {"name", "type", "material", "path"}, "object '" + name + "'");
-    fail("object '" + name + "': FBX meshes need the FBX reader, which this build does not have yet");
+    if (!o.contains("path") || !o.at("path").isString()) fail("object '" + name + "' should have a 'path' string");
+    std::string ferr;
+    if (!readFbxMesh(baseDir + "/" + o.at("path").string, mesh.tris, &ferr)) fail("object '" + name + "': " + ferr);
   } else if (type == "primitive") {
     onlyKeys(o, {"name", "type", "material", "shape"}, "object '" + name + "'");
     if (!o.contains("shape") || !o.at("shape").isString()) fail("object '" + name + "' should have a 'shape' string");
@@ -419,11 +426,6 @@ void walkWorld(Value const& node, State& st, Scene& sc) {  // parseWorldTranform
   }
 }
 
-std::string directoryOf(std::string const& path) {
-  size_t const p = path.find_last_of('/');
-  return p == std::string::npos ? std::string(".") : path.substr(0, p);
-}
-
 }  // namespace
 
 // ---- PNG reader: 8-bit grey / RGB / RGBA, non-interlaced (what the env maps of the reference's scenes are) ------
@@ -532,7 +534,7 @@ bool loadJsonScene(std::string const& path, JsonScene& out, std::string* error) 
     if (!data.at("materials").isArray()) fail("'materials' should be a JSON array");
     for (auto const& m : data.at("materials").array) parseMaterial(m, st);
     if (!data.at("objects").isArray()) fail("'objects' should be a JSON array");
-    for (auto const& o : data.at("objects").array) parseObject(o, st);
+    for (auto const& o : data.at("objects").array) parseObject(o, st, directoryOf(path));
     if (!data.at("lights").isArray()) fail("'lights' should be a JSON array");
     for (auto const& l : data.at("lights").array) parseLight(l, st);
     if (!data.at("envlight").isString()) fail("'envlight' should be a path string");

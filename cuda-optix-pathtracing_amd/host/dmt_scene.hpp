@@ -85,13 +85,15 @@ Scene randomTriangleScene(size_t triangleCount, uint64_t seed = 0x5EED1234ull);
 // JSON scene front-end: the reference's scene description (src/core/private/core-parser.cpp:256-1455;
 // keys camera / film / textures / materials / objects / lights / envlight / transforms / world) flattened to the
 // megakernel's upload arrays.  Returns false and a message for anything the reference's parser rejects, and for
-// what this path cannot represent yet (image textures, normal maps, FBX objects).
+// what this path cannot represent yet (image textures, normal maps).
 struct JsonScene {
   Scene scene;
   int maxDepth = 5;          // camera "max-depth" (core-types.h:30)
   int samplesPerPixel = 1;   // film "samples"   (core-types.h:28)
 };
 bool loadJsonScene(std::string const& path, JsonScene& out, std::string* error = nullptr);
+// binary FBX (Kaydara 7100+): first mesh, fan-triangulated, Model TRS and unit scale applied (host/dmt_fbx.cpp)
+bool readFbxMesh(std::string const& path, std::vector<Triangle>& out, std::string* error = nullptr);
 // 8-bit grey / RGB / RGBA non-interlaced PNG -> RGB floats, byte / 255 as the reference's loadImageAsRGB
 // (core-parser.cpp:156-167)
 bool readPngRgb(std::string const& path, std::vector<float>& rgb, int& width, int& height, std::string* error = nullptr);

@@ -81,6 +81,19 @@ class HostScene:
         return self
 
 
+def read_fbx(path):
+    """First mesh of a binary FBX file -> float32 [n, 3, 3] triangle list (host/dmt_fbx.cpp)."""
+    L = load_host_library()
+    L.dmt_host_read_fbx.restype = C.c_int64
+    err = C.create_string_buffer(1024)
+    n = L.dmt_host_read_fbx(str(path).encode(), None, C.c_uint64(0), err, C.c_uint64(len(err)))
+    if n < 0:
+        raise ValueError(err.value.decode())
+    out = np.zeros((n, 3, 3), np.float32)
+    L.dmt_host_read_fbx(str(path).encode(), out.ctypes.data_as(C.c_void_p), C.c_uint64(n), err, C.c_uint64(len(err)))
+    return out
+
+
 def load_json(path):
     """The reference's JSON scene description (core-parser.cpp) -> HostScene (+ .max_depth, .spp, .env_rgb).
     Raises ValueError with the loader's message when the file is rejected."""

@@ -71,7 +71,7 @@ def _variant(tmp_path, edit):
     (lambda d: d["materials"][0].update(diffuse="paint"), "existing named texture"),         # :497
     (lambda d: d["objects"][0].update(material="nope"), "unknown material"),
     (lambda d: d["objects"][0].update(shape="torus"), "unrecognized shape"),
-    (lambda d: d["objects"][0].update(type="FBX", path="x.fbx") or d["objects"][0].pop("shape"), "FBX"),
+    (lambda d: d["objects"][0].update(type="FBX", path="x.fbx") or d["objects"][0].pop("shape"), "cannot open"),
     (lambda d: d["lights"][0].update(radius=1), "extraneous key 'radius'"),                  # :1001-1012
     (lambda d: d["lights"][1].update(type="area"), "unrecognized type"),
     (lambda d: d["transforms"][0].update(name=""), "non-empty 'name'"),                      # :836
@@ -112,3 +112,67 @@ def test_json_reader_details(pkg, tmp_path):
     (tmp_path / "bad.json").write_text(text[:-3])
     with pytest.raises(ValueError):
         pkg.host_scene.load_json(tmp_path / "bad.json")
+
+
+# ---------------------------------------------------------------------------------------------
+# binary FBX reader (replaces the FBX SDK call of MeshFbxParser::ImportFBX).  Parity unpinned: no SDK
+# here; checked against files written by tools/make_fbx_fixture.py and the structure of the reference's asset.
+# ---------------------------------------------------------------------------------------------
+sys.path.insert(0, str(ROOT / "tools"))
+import make_fbx_fixture as fbxfix  # noqa: E402
+
+
+def test_fbx_reader_fixture(pkg, tmp_path):
+    v, polys = fbxfix.uv_sphere()
+    got = pkg.host_scene.read_fbx(GOLDEN / "fbx" / "uv_sphere_trs.fbx")
+    want = fbxfix.expected_triangles(v, polys, **fbxfix.FIXTURE)
+    assert got.shape == want.shape == (80, 3, 3)         # 8 + 8 pole triangles + 32 quads fan-triangulated
+    assert np.abs(got - want).max() < 1e-6
+    # the committed fixture is what the writer produces (regenerable)
+    fbxfix.write(tmp_path / "again.fbx", v, polys, **fbxfix.FIXTURE)
+    assert (tmp_path / "again.fbx").read_bytes() == (GOLDEN / "fbx" / "uv_sphere_trs.fbx").read_bytes()
+
+
+def test_fbx_reader_rejects_garbage(pkg, tmp_path):
+    (tmp_path / "a.fbx").write_bytes(b"; FBX 7.4.0 project file\n")
+    with pytest.raises(ValueError, match="not a binary FBX"):
+        pkg.host_scene.read_fbx(tmp_path / "a.fbx")
+    good = (GOLDEN / "fbx" / "ball.fbx").read_bytes()
+    (tmp_path / "b.fbx").write_bytes(good[:200])
+    with pytest.raises(ValueError):
+        pkg.host_scene.read_fbx(tmp_path / "b.fbx")
+    with pytest.raises(ValueError, match="cannot open"):
+        pkg.host_scene.read_fbx(tmp_path / "missing.fbx")
+
+
+def test_fbx_reader_on_the_reference_asset(pkg):
+    """scenes/sphere.fbx of the reference (BASELINE config 3): present in the build container only."""
+    asset = Path("/root/reference/scenes/sphere.fbx")
+    if not asset.exists():
+        pytest.skip("reference assets are not on this machine")
+    t = pkg.host_scene.read_fbx(asset)
+    assert t.shape == (480, 3, 3)                         # 1440 polygon-vertex indices, all triangles
+    r = np.linalg.norm(t.reshape(-1, 3), axis=1)
+    assert abs(r.max() - 100.0) < 1e-3                    # unit mesh x Lcl Scaling 100 (Blender's centimetres)
+    # closed surface: every undirected edge is shared by exactly two triangles
+    q = np.round(t.reshape(-1, 3) * 1e3).astype(np.int64)
+    ids = {tuple(p): i for i, p in enumerate(map(tuple, np.unique(q, axis=0)))}
+    tri = np.array([ids[tuple(p)] for p in q]).reshape(-1, 3)
+    edges = {}
+    for a, b, c in tri:
+        for e in ((a, b), (b, c), (c, a)):
+            k = (min(e), max(e))
+            edges[k] = edges.get(k, 0) + 1
+    assert set(edges.values()) == {2}
+
+
+def test_json_scene_with_fbx_object(pkg):
+    """BASELINE config 3 in miniature: an FBX mesh under an env map (scenes/fbx_example.json's shape)."""
+    s = pkg.host_scene.load_json(GOLDEN / "json_scene" / "ball_envmap.json")
+    ball = pkg.host_scene.read_fbx(GOLDEN / "fbx" / "ball.fbx")
+    assert s.tri_count == ball.shape[0] + 2
+    assert s.mat_id.tolist() == [1] * 2 + [0] * ball.shape[0]   # key order: position-floor < position-light < position-obj
+    moved = ball + np.array([0, 3, 0], np.float32)
+    got = np.stack([s.xs[2:, :3], s.ys[2:, :3], s.zs[2:, :3]], -1)   # [tri, vertex, xyz]
+    assert np.abs(got - moved).max() < 1e-6
+    assert s.env_rgb is not None and s.lights.shape[0] == 1 and s.max_depth == 8

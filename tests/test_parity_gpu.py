@@ -635,9 +635,11 @@ def test_envmap_clear_restores_constant_environment(renderer, O):
 # ---------------------------------------------------------------------------------------------
 # JSON scene front-end end to end: file -> host loader -> HIP render == oracle render of the same arrays
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("accel", [0, 1])
-def test_json_scene_renders_like_the_oracle(renderer, pkg, O, accel):
-    hs = pkg.host_scene.load_json(GOLDEN / "json_scene" / "three_boxes.json")
+@pytest.mark.parametrize("name, accel", [("three_boxes.json", 0), ("three_boxes.json", 1), ("ball_envmap.json", 1)])
+def test_json_scene_renders_like_the_oracle(renderer, pkg, O, name, accel):
+    """three_boxes: primitives, three material kinds, spot + point light, env map.  ball_envmap: BASELINE config 3 in
+    miniature (FBX mesh, conductor, env map: the NEE + MIS path), through the BVH kernel."""
+    hs = pkg.host_scene.load_json(GOLDEN / "json_scene" / name)
     osc = O.Scene(hs.xs, hs.ys, hs.zs, hs.mat_id, hs.bsdfs, hs.lights, hs.inf_lights, hs.camera)
     osc.set_envmap(hs.env_rgb)
     renderer.upload_scene(hs)
