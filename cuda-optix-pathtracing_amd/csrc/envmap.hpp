@@ -133,7 +133,9 @@ DMT_DEV EnvSampleDev env_sample(EnvView const& e, f2 u) {  // core-light.cpp:394
   if (mapPdf == 0.f) return r;
   float const phi = fminf(fmaxf(1.f - 2.f * kPi * d0, -kPi), kPi);
   float const theta = fminf(fmaxf(kPi * d1, 0.f), kPi);
-  float const sp = sinf(phi), cp = cosf(phi), st = sinf(theta), ct = cosf(theta);
+  float sp, cp, st, ct;
+  sincos_bounded(phi, sp, cp);
+  sincos_bounded(theta, st, ct);
   r.wi = env_rotate(mk3(sp * ct, sp * st, cp), -e.qx, -e.qy, -e.qz, e.qw, e.qx, e.qy, e.qz, e.qw);
   r.pdf = mapPdf / (4 * kPi);
   r.ok = true;

@@ -121,7 +121,14 @@ DMT_DEV float h2f(uint32_t h) {  // exact; v_cvt_f32_f16 with fp16 denormals ena
   _Float16 hv = __builtin_bit_cast(_Float16, (unsigned short)(h & 0xFFFFu));
   return float(hv);
 }
-DMT_DEV float q16(float f) { return h2f(f2h(f)); }
+// fp32 -> fp16 -> fp32.  For magnitudes in fp16's normal range [2^-14, 65520) the codec's round-half-up is
+// "add half of the 13 dropped mantissa bits, truncate" on the fp32 encoding (a mantissa carry runs into the
+// exponent by itself): 3 integer ops instead of ~55.  Everything else takes the full codec.
+DMT_DEV float q16(float f) {
+  uint32_t const u = __float_as_uint(f), a = u & 0x7FFFFFFFu;
+  if (a >= 0x38800000u && a < 0x477FF000u) return __uint_as_float((u + 0x1000u) & 0xFFFFE000u);
+  return h2f(f2h(f));
+}
 DMT_DEV f3 q16(f3 v) { return mk3(q16(v.x), q16(v.y), q16(v.z)); }
 
 // octahedral decode                                             CC/private/encoding.cu:39-60
@@ -490,16 +497,45 @@ DMT_DEV Hit hit_finish(TriPost const& P, float u, float v, f3 rayDir) {
   h.matId = P.matId;
   return h;
 }
+// nextafterf(x, up ? +inf : -inf) for finite x, as integer arithmetic on the encoding (the library routine handles
+// NaNs, infinities and a general target: 19 instructions per call, six calls per bounce)
+DMT_DEV float next_float(float x, bool up) {
+  uint32_t const b = __float_as_uint(x);
+  if ((b & 0x7FFFFFFFu) == 0u) return __uint_as_float(up ? 0x00000001u : 0x80000001u);
+  bool const positive = (b >> 31) == 0u;
+  return __uint_as_float(positive == up ? b + 1u : b - 1u);
+}
 // CC extra_math.cuh:36-59
 DMT_DEV f3 offset_ray_origin(f3 p, f3 error, f3 ng, f3 w) {
   float const d = dot(abs3(ng), error);
   f3 offset = ng * d;
   if (dot(w, ng) < 0.f) offset = -offset;
   f3 po = p + offset;
-  po.x = nextafterf(po.x, offset.x > 0 ? kInf : -kInf);
-  po.y = nextafterf(po.y, offset.y > 0 ? kInf : -kInf);
-  po.z = nextafterf(po.z, offset.z > 0 ? kInf : -kInf);
+  po.x = next_float(po.x, offset.x > 0);
+  po.y = next_float(po.y, offset.y > 0);
+  po.z = next_float(po.z, offset.z > 0);
   return po;
+}
+
+// sin and cos of a BOUNDED angle (|x| < ~1e3; every angle on this path is within [-2 pi, 2 pi]): three-constant
+// Cody-Waite reduction to [-pi/4, pi/4] and the classic single-precision minimax polynomials, ~1 ulp, i.e. the
+// same accuracy class as libm's sinf/cosf on both sides of the parity tests.  The library functions carry a
+// Payne-Hanek path for huge arguments that is never taken here but was a THIRD of the megakernel's code
+// (3 300 of 9 900 instructions for three call sites): the kernel no longer fit the instruction cache it shares
+// with the neighbouring CU.
+DMT_DEV void sincos_bounded(float x, float& sn, float& cs) {
+  float const q = rintf(x * 0.636619772367581343f);  // x * 2/pi
+  float r = fma_(q, -1.5703125f, x);
+  r = fma_(q, -4.837512969970703125e-4f, r);
+  r = fma_(q, -7.54978995489188216e-8f, r);
+  float const r2 = r * r;
+  float const sp = fma_(fma_(fma_(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+  float const cp = fma_(fma_(fma_(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f), r2 * r2,
+                        fma_(-0.5f, r2, 1.0f));
+  int const n = int(q) & 3;
+  float const a = (n & 1) ? cp : sp, b = (n & 1) ? sp : cp;
+  sn = (n & 2) ? -a : a;
+  cs = ((n + 1) & 2) ? -b : b;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -517,7 +553,9 @@ DMT_DEV f2 sample_uniform_disk(f2 u) {  // :135-155 (the 3pi/4 branch is the ref
     rho = b;
     phi = (3 * kPi / 4) * (a / b);
   }
-  return mk2(rho * cosf(phi), rho * sinf(phi));
+  float sn, cs;
+  sincos_bounded(phi, sn, cs);
+  return mk2(rho * cs, rho * sn);
 }
 DMT_DEV f3 sample_cos_hemisphere(f3 n, f2 u, float& pdf) {  // :157-167
   f2 const r = sample_uniform_disk(u);
@@ -531,7 +569,9 @@ DMT_DEV f3 sample_uniform_sphere(f2 rnd) {  // :123-133
   float const z = 1.0f - 2.0f * rnd.x;
   float const r = safe_sqrt(1.f - z * z);
   float const phi = 2 * kPi * rnd.y;
-  return mk3(r * cosf(phi), r * sinf(phi), z);
+  float sn, cs;
+  sincos_bounded(phi, sn, cs);
+  return mk3(r * cs, r * sn, z);
 }
 // :86-121.  `xy *= s` in the reference assigns s to both components (common_math.cuh:349-353).
 DMT_DEV f3 sample_uniform_cone(f3 N, float omc, f2 rnd, float& cosTheta, float& pdf, int& delta) {
@@ -901,8 +941,8 @@ DMT_DEV f3 tangent_from_phi(f3 ns, float phi0) {  // bsdf.cu:279-294
   f3 const ref = fabsf(ns.x) < 0.999f ? mk3(1.0f, 0.0f, 0.0f) : mk3(0.0f, 1.0f, 0.0f);
   f3 const t = normalize(cross(ref, ns));
   f3 const bt = cross(ns, t);
-  float const s = sinf(phi0);
-  float const c = cosf(phi0);
+  float s, c;
+  sincos_bounded(phi0, s, c);
   return c * t + s * bt;
 }
 DMT_DEV f3 sample_ggx_vndf(f3 wo, f2 u, float ax, float ay) {  // bsdf.cu:303-329
