@@ -101,6 +101,7 @@ DMT_DEV int env_find_interval(int sz, float const* cdf, float u) {  // core-math
   return r < 0 ? 0 : (r > sz - 2 ? sz - 2 : r);
 }
 DMT_DEV float env_sample1d(float const* absf, float const* cdf, int n, float integral, float u, float& pdf, int& off) {
+#pragma clang fp reciprocal(off)  // uv picks a texel downstream: keep these divisions as written (build uses -freciprocal-math)
   off = env_find_interval(n, cdf, u);
   float const c0 = cdf[off], c1 = cdf[off + 1];
   float du = u - c0;

@@ -35,8 +35,16 @@ DMT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 DMT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 DMT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 DMT_DEV f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
-DMT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
-DMT_DEV f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+// Vector divisions go through v_rcp_f32 (1 ulp) and a multiply.  The compiler's own "fast" fp32 division (the
+// build runs with -fno-hip-fp32-correctly-rounded-divide-sqrt) wraps the same v_rcp in a range
+// rescue for |divisor| > 2^96 that costs four more instructions per component and never triggers here.
+DMT_DEV f3 operator/(f3 a, float s) {
+  float const inv = __builtin_amdgcn_rcpf(s);
+  return mk3(a.x * inv, a.y * inv, a.z * inv);
+}
+DMT_DEV f3 operator/(f3 a, f3 b) {
+  return mk3(a.x * __builtin_amdgcn_rcpf(b.x), a.y * __builtin_amdgcn_rcpf(b.y), a.z * __builtin_amdgcn_rcpf(b.z));
+}
 DMT_DEV f3 operator+(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
 DMT_DEV f3 operator+(float s, f3 a) { return mk3(a.x + s, a.y + s, a.z + s); }
 DMT_DEV f3 operator-(f3 a, float s) { return mk3(a.x - s, a.y - s, a.z - s); }
@@ -46,7 +54,7 @@ DMT_DEV float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
 DMT_DEV f3 cross(f3 a, f3 b) {
   return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-DMT_DEV float rsqrt_ieee(float x) { return 1.0f / sqrtf(x); }  // host rsqrtf of the reference
+DMT_DEV float rsqrt_ieee(float x) { return __builtin_amdgcn_rsqf(x); }  // the reference's rsqrtf; v_rsq_f32, 1 ulp
 DMT_DEV f3 normalize(f3 a) {                                   // CC common_math.cuh:297-300
   float const inv = rsqrt_ieee(a.x * a.x + a.y * a.y + a.z * a.z);
   return mk3(a.x * inv, a.y * inv, a.z * inv);

@@ -578,11 +578,12 @@ def test_envmap_functions_vs_oracle(renderer, O):
         renderer.clear_envmap()
     a = O.envmap_sample(img, q, u)
     e = O.envmap_eval(img, q, wi)
-    # the two binary searches and the table reads are exact: uv, pdf, texel bit-identical
+    # the two binary searches and the table reads are exact; uv and pdf carry v_rcp-based divisions (1-2 ulp), and
+    # a uv within an ulp of a texel border may pick the neighbouring texel
     assert np.array_equal(g["ok"], a["ok"])
-    assert np.array_equal(g["uv"], a["uv"])
-    assert np.allclose(g["pdf"], a["pdf"], rtol=2e-6, atol=0)        # one v_rcp-based division
-    assert np.array_equal(g["Le"], a["Le"])
+    assert np.abs(g["uv"] - a["uv"]).max() < 3e-7
+    assert np.allclose(g["pdf"], a["pdf"], rtol=2e-6, atol=0)
+    assert (g["Le"] == a["Le"]).all(axis=1).mean() > 0.999
     assert np.abs(g["wi"] - a["wi"]).max() < 2e-6                     # sinf/cosf + quaternion with FMA contraction
     # evaluation by direction: the texel can flip for directions within rounding of a texel border
     same = (g["Le_dir"] == e["Le"]).all(axis=1)
