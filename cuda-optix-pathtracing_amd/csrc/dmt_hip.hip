@@ -879,6 +879,7 @@ __global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats(RenderParams P)
 // instantiations, so that the register allocation of the default kernels is not touched.
 __global__ void __launch_bounds__(256, 3) k_megakernel_env(RenderParams P) { megakernel_body<false, false, true>(); }
 __global__ void __launch_bounds__(256, 2) k_megakernel_bvh_env(RenderParams P) { megakernel_body_bvh<false, true>(); }
+__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats_env(RenderParams P) { megakernel_body_bvh<true, true>(); }
 
 // ---------------------------------------------------------------------------------------------
 // device unit-test kernels
@@ -1721,7 +1722,10 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
       HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dstats), 16 * sizeof(unsigned long long)));
       HIP_TRY(ctx, hipMemsetAsync(dstats, 0, 16 * sizeof(unsigned long long), ctx->stream));
       P.stats = dstats;
-      hipLaunchKernelGGL(k_megakernel_bvh_stats, dim3(blocks), dim3(256), 0, ctx->stream, P);
+      if (useEnv)
+        hipLaunchKernelGGL(k_megakernel_bvh_stats_env, dim3(blocks), dim3(256), 0, ctx->stream, P);
+      else
+        hipLaunchKernelGGL(k_megakernel_bvh_stats, dim3(blocks), dim3(256), 0, ctx->stream, P);
       hipError_t e = hipGetLastError();
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e == hipSuccess) e = hipMemcpy(stats6, dstats, size_t(nstats) * sizeof(unsigned long long), hipMemcpyDeviceToHost);

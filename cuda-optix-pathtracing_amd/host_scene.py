@@ -142,3 +142,78 @@ def write_mean_and_mse(mean, m2, base_name):
                                                          C.c_uint32(w), C.c_uint32(h), str(base_name).encode())
     if rc != 0:
         raise RuntimeError(f"writing {base_name}.png failed")
+
+
+class ArrayScene:
+    """A scene assembled from numpy arrays (same attributes as HostScene)."""
+
+    def __init__(self, xs, ys, zs, mat_id, bsdfs, lights, inf_lights, camera, env_rgb=None):
+        self.xs, self.ys, self.zs = (np.ascontiguousarray(a, np.float32).reshape(-1, 4) for a in (xs, ys, zs))
+        self.mat_id = np.ascontiguousarray(mat_id, np.uint32)
+        self.bsdfs = np.ascontiguousarray(bsdfs, np.uint8).reshape(-1, 32)
+        self.lights = np.ascontiguousarray(lights, np.uint8).reshape(-1, 32)
+        self.inf_lights = np.ascontiguousarray(inf_lights, np.uint8).reshape(-1, 32)
+        self.camera = np.ascontiguousarray(camera, np.uint8).reshape(44).copy()
+        self.env_rgb = None if env_rgb is None else np.ascontiguousarray(env_rgb, np.float32)
+        self.env_quat, self.env_scale = np.array([0, 0, 0, 1], np.float32), 1.0
+
+    tri_count = HostScene.tri_count
+    width = HostScene.width
+    height = HostScene.height
+    set_resolution = HostScene.set_resolution
+
+
+def _record(fn, *args):
+    out = np.zeros(32, np.uint8)
+    fn(*args, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def _f3(v):
+    return np.ascontiguousarray(v, np.float32).ctypes.data_as(C.c_void_p)
+
+
+def synthetic_sky(height=512):
+    """Deterministic HDR equirectangular map (height x 2*height x 3): horizon gradient + a small, very bright sun."""
+    h, w = int(height), 2 * int(height)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    v = y / h
+    sky = np.stack([0.35 + 0.4 * v, 0.45 + 0.35 * v, 0.7 + 0.2 * v], -1).astype(np.float32)
+    sun = np.exp(-(((x - 0.3 * w) / (0.01 * w)) ** 2 + ((y - 0.62 * h) / (0.02 * h)) ** 2)).astype(np.float32)
+    return (sky + sun[..., None] * np.array([900.0, 800.0, 600.0], np.float32)).astype(np.float32)
+
+
+def sphere_envmap_scene(width, height, lat=64, lon=128, env_height=512):
+    """BASELINE config 3 with synthetic assets (the reference's sphere.fbx / veranda map do not travel): a UV sphere
+    (conductor) on a large Oren-Nayar ground plane under an importance-sampled HDR sky, one spot light."""
+    L = load_host_library()
+    th = np.pi * np.arange(lat + 1, dtype=np.float64) / lat
+    ph = 2 * np.pi * np.arange(lon + 1, dtype=np.float64) / lon
+    P = np.stack([np.outer(np.sin(th), np.cos(ph)), np.outer(np.sin(th), np.sin(ph)), np.outer(np.cos(th), np.ones_like(ph))], -1)
+    P = (P * 1.0 + np.array([0.0, 4.0, 0.0])).astype(np.float32)
+    tris = []
+    for i in range(lat):
+        for j in range(lon):
+            a, b, c, d = P[i, j], P[i + 1, j], P[i + 1, j + 1], P[i, j + 1]
+            if i > 0:
+                tris.append((a, b, d))
+            if i < lat - 1:
+                tris.append((b, c, d))
+    g = 40.0
+    q = np.array([[-g, 4 - g, -1.0], [g, 4 - g, -1.0], [-g, 4 + g, -1.0], [g, 4 + g, -1.0]], np.float32)
+    tris += [(q[0], q[3], q[2]), (q[0], q[1], q[3])]
+    T = np.array(tris, np.float32)                      # [n, 3 vertices, xyz]
+    n = T.shape[0]
+    xs, ys, zs = (np.concatenate([T[:, :, k], np.zeros((n, 1), np.float32)], 1) for k in range(3))
+    mat = np.zeros(n, np.uint32)
+    mat[-2:] = 1
+    bsdfs = np.stack([_record(L.dmt_host_make_ggx_conductor, _f3([0.18299, 0.42108, 1.37340]), _f3([3.42420, 2.34590, 1.77040]),
+                              C.c_float(0.0), C.c_float(0.2), C.c_float(0.15)),
+                      _record(L.dmt_host_make_oren_nayar, _f3([0.55, 0.5, 0.45]), C.c_float(0.8))])
+    lights = np.stack([_record(L.dmt_host_make_spot_light, _f3([30, 30, 28]), _f3([-2.0, 1.5, 3.0]), _f3([0.5, 0.65, -0.6]),
+                               C.c_float(np.cos(np.radians(25))), C.c_float(np.cos(np.radians(35))), C.c_float(1e-3))])
+    cam = np.zeros(44, np.uint8)
+    cam[:24] = np.array([0, 1, -0.05, 0, 0, 0], np.float32).view(np.uint8)
+    cam[24:36] = np.array([width, height, 1], np.int32).view(np.uint8)
+    cam[36:44] = np.array([28.0, 36.0], np.float32).view(np.uint8)
+    return ArrayScene(xs, ys, zs, mat, bsdfs, lights, np.zeros((0, 32), np.uint8), cam, synthetic_sky(env_height))

@@ -674,3 +674,27 @@ def test_cli_renders_a_json_scene(tmp_path):
     assert (tmp_path / "output-8.png").stat().st_size > 500 and (tmp_path / "output-8_sqrt_mse.png").exists()
     r = subprocess.run([str(exe), "--scene", str(tmp_path / "missing.json")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot open" in r.stderr
+
+
+def test_sphere_envmap_workload_scene(renderer, pkg, O):
+    """The synthetic stand-in for BASELINE config 3 that bench.py offers (sphere + ground under an HDR sky), small."""
+    sc = pkg.host_scene.sphere_envmap_scene(48, 48, lat=8, lon=16, env_height=16)
+    osc = O.Scene(sc.xs, sc.ys, sc.zs, sc.mat_id, sc.bsdfs, sc.lights, sc.inf_lights, sc.camera)
+    osc.set_envmap(sc.env_rgb)
+    renderer.upload_scene(sc)
+    renderer.set_limits(8)
+    renderer.set_accel(1)
+    renderer.set_partition(0, 1)
+    try:
+        renderer.film_clear()
+        renderer.render(24)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
+    finally:
+        renderer.set_accel(0)
+        renderer.clear_envmap()
+    om, om2 = O.render(osc, 24, max_depth=8, threads=8)[:2]
+    assert np.array_equal(m2[..., 3], om2[..., 3])
+    scale = float(om[..., :3].mean())
+    assert scale > 0.2
+    assert float(np.sqrt(np.mean((mean[..., :3] - om[..., :3]) ** 2))) < 2e-3 * scale
