@@ -52,7 +52,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "dmt_ctx_create", "dmt_ctx_destroy", "dmt_last_error", "dmt_upload_triangles", "dmt_upload_bsdfs",
     "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_partition", "dmt_set_chunk", "dmt_render_profile",
-    "dmt_upload_envmap", "dmt_clear_envmap", "dmt_envmap_tables", "dmt_test_envmap",
+    "dmt_upload_area_lights", "dmt_upload_envmap", "dmt_clear_envmap", "dmt_envmap_tables", "dmt_test_envmap",
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
     "dmt_render", "dmt_render_stats", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
     "dmt_test_sampler", "dmt_test_camera_rays", "dmt_test_bsdf", "dmt_test_light", "dmt_test_half",
@@ -165,10 +165,19 @@ class Renderer:
         self.upload_bsdfs(scene.bsdfs)
         self.upload_lights(scene.lights, scene.inf_lights)
         self.set_camera(scene.camera)
+        if getattr(scene, "area_tri", None) is not None and len(scene.area_tri):
+            self.upload_area_lights(scene.area_tri, scene.area_le)
         if getattr(scene, "env_rgb", None) is not None:
             self.upload_envmap(scene.env_rgb, scene.env_quat, scene.env_scale)
         else:
             self.clear_envmap()
+
+    def upload_area_lights(self, tri, le):
+        tri = np.ascontiguousarray(tri, np.uint32).reshape(-1)
+        le = np.ascontiguousarray(le, np.float32).reshape(-1, 3)
+        assert tri.shape[0] == le.shape[0]
+        self._check(self._lib.dmt_upload_area_lights(self._ctx, _p(tri), _p(le), C.c_uint32(tri.shape[0])),
+                    "dmt_upload_area_lights")
 
     def upload_envmap(self, rgb, quat=(0, 0, 0, 1), scale=1.0):
         rgb = np.ascontiguousarray(rgb, np.float32)

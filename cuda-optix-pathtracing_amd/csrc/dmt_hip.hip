@@ -57,6 +57,11 @@ struct RenderParams {
   uint32_t* errorFlag;     // set if a bounded wait gives up
   int maxDepth;
   EnvView env;                // A18 env map (w == 0: none); read by the *_env kernels only
+  // SURVEY 8f-3 emissive triangles; read by the *_area kernels only
+  uint32_t const* areaOf;     // [triCount] index into areaTri / areaLe, 0xFFFFFFFF = not emissive
+  uint32_t const* areaTri;    // [areaCount] ORIGINAL triangle index
+  float const* areaLe;        // [areaCount] rgb radiance
+  uint32_t areaCount;
   unsigned long long* stats;  // stats build only: samples, closest rays, shadow rays, node visits, triangle tests, bounces
 };
 
@@ -163,7 +168,54 @@ DMT_DEV void path_begin(PathState& st, CameraXf const& cam, SamplerParams const&
 // Everything between two ray casts (T/megakernel/megakernel.cu:135-295).  Returns true when the
 // path ends.  May leave a pending shadow ray (st.hasShadow) whose contribution st.C is added once
 // visibility is known.
-template <bool ENV = false>
+// ---- emissive triangles.  No reference implementation exists; semantics are pbrt-v4's, which the
+// reference's scenes/cornell-box.pbrt is written for: DiffuseAreaLight, one-sided on n = normalize(cross(p1 - p0,
+// p2 - p0)); uniform point sampling (SampleUniformTriangle); light chosen uniformly among [point/spot lights...,
+// emissive triangles...]; power-heuristic MIS between light and BSDF sampling; emission seen directly by camera rays
+// and after delta bounces.
+struct AreaSampleDev {
+  f3 wi;
+  float dist, pdf;
+  bool ok;
+};
+DMT_DEV AreaSampleDev area_sample(TriPost const& P, f3 p, f2 u) {
+  AreaSampleDev r;
+  r.ok = false, r.dist = 0.f, r.pdf = 0.f, r.wi = mk3(0, 0, 0);
+  f3 const p0 = mk3(P.p0x, P.p0y, P.p0z), p1 = mk3(P.p1x, P.p1y, P.p1z), p2 = mk3(P.p2x, P.p2y, P.p2z);
+  float b0, b1;
+  if (u.x < u.y) {
+    b0 = u.x / 2;
+    b1 = u.y - b0;
+  } else {
+    b1 = u.y / 2;
+    b0 = u.x - b1;
+  }
+  f3 const q = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
+  f3 const c = cross(p1 - p0, p2 - p0);
+  float const len = sqrtf(dot(c, c));
+  if (!(len > 0.f)) return r;
+  f3 const d = q - p;
+  float const d2 = dot(d, d);
+  if (!(d2 > 0.f)) return r;
+  r.dist = sqrtf(d2);
+  r.wi = d / r.dist;
+  float const cosL = -dot(c / len, r.wi);
+  if (!(cosL > 0.f)) return r;  // one-sided
+  r.pdf = d2 / (cosL * (0.5f * len));
+  r.ok = true;
+  return r;
+}
+DMT_DEV float area_pdf(TriPost const& P, f3 rayD, float t) {
+  f3 const p0 = mk3(P.p0x, P.p0y, P.p0z), p1 = mk3(P.p1x, P.p1y, P.p1z), p2 = mk3(P.p2x, P.p2y, P.p2z);
+  f3 const c = cross(p1 - p0, p2 - p0);
+  float const len = sqrtf(dot(c, c));
+  if (!(len > 0.f)) return 0.f;
+  float const cosL = -dot(c / len, rayD);
+  if (!(cosL > 0.f)) return 0.f;
+  return (t * t) / (cosL * (0.5f * len));
+}
+
+template <bool ENV = false, bool AREA = false>
 DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv) {
   SceneView const sc = load_scene(k);
   int const maxDepth = kargs(k)->maxDepth;
@@ -188,10 +240,29 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
     }
     return true;
   }
-  if (st.depth >= maxDepth) return true;  // :154-158
-
   f3 const rd = ray_dir(st);
   Hit const hit = hit_finish(sc.post[bestTri], bu, bv, rd);
+  uint32_t nAll = sc.lightCount;  // lights the NEE chooses among
+  if constexpr (AREA) {
+    KArgs const ka = kargs(k);
+    nAll += ka->areaCount;
+    uint32_t const ai = ka->areaOf[bestTri];
+    if (ai != 0xFFFFFFFFu) {  // emitted radiance of the surface the path ray hit
+      f3 const o = mk3(st.rp.ox.x, st.rp.oy.x, st.rp.oz.x);
+      float const pl = area_pdf(sc.post[bestTri], rd, dot(hit.pos - o, rd));
+      if (pl > 0.f) {
+        f3 const Le = mk3(ka->areaLe[3 * ai], ka->areaLe[3 * ai + 1], ka->areaLe[3 * ai + 2]);
+        if (st.depth == 0 || st.lastSpecular) {
+          st.L = st.L + st.beta * Le;
+        } else {
+          float const a = st.lastPdf, b = pl / float(nAll);
+          st.L = st.L + st.beta * Le * ((a * a) / (a * a + b * b));
+        }
+      }
+    }
+  }
+  if (st.depth >= maxDepth) return true;  // :154-158
+
   f3 const wo = -rd;
   Bsdf const b = bsdf_prepare(sc.bsdfs[hit.matId], hit.normal, wo);  // :165-166
 
@@ -218,10 +289,32 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
       }
     }
   }
-  if (!envNee && sc.lightCount > 0) {
-    uint32_t const li = pick_index(uLight, sc.lightCount);
+  bool areaNee = false;
+  if constexpr (AREA) {
+    uint32_t const li = pick_index(uLight, nAll);
+    areaNee = li >= sc.lightCount;
+    if (areaNee) {
+      KArgs const ka = kargs(k);
+      uint32_t const ai = li - sc.lightCount;
+      AreaSampleDev const as = area_sample(sc.post[ka->areaTri[ai]], hit.pos, uLight2);
+      if (as.ok) {
+        float bsdfPdf = 0.f;
+        f3 const f = eval_bsdf(b, wo, as.wi, hit.normal, hit.normal, bsdfPdf) * b.weight;
+        if (!is_zero(f)) {
+          f3 const Le = mk3(ka->areaLe[3 * ai], ka->areaLe[3 * ai + 1], ka->areaLe[3 * ai + 2]);
+          float const a = as.pdf / float(nAll), bb = bsdfPdf;
+          put_C(st.beta * (Le * f * (((a * a) / (a * a + bb * bb)) / a)));
+          set_shadow_ray(st, offset_ray_origin(hit.pos, hit.error, hit.normal, as.wi), as.wi);
+          st.smax = as.dist * 0.999f;
+          st.hasShadow = true;
+        }
+      }
+    }
+  }
+  if (!envNee && !areaNee && sc.lightCount > 0) {
+    uint32_t const li = pick_index(uLight, AREA ? nAll : sc.lightCount);
     Rec32 const light = sc.lights[li];
-    float const pmf = (ENV ? 0.5f : 1.f) / float(sc.lightCount);
+    float const pmf = (ENV ? 0.5f : 1.f) / float(AREA ? nAll : sc.lightCount);
     LightSample const ls = sample_light(light, hit.pos, uLight2, st.lastT, hit.normal);
     if (ls.valid()) {
       float bsdfPdf = 0.f;
@@ -248,7 +341,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
   BsdfSample const bs = sample_bsdf(b, wo, hit.normal, hit.normal, u2, uc);
   if (!bs.valid()) return true;
   st.lastT = bs.refract;
-  if constexpr (ENV) st.lastPdf = bs.pdf, st.lastSpecular = bs.delta;
+  if constexpr (ENV || AREA) st.lastPdf = bs.pdf, st.lastSpecular = bs.delta;
   set_ray(st, offset_ray_origin(hit.pos, hit.error, hit.normal, bs.wi), bs.wi);
   st.beta = st.beta * (bs.f * fabsf(dot(bs.wi, hit.normal)) / bs.pdf);
   float const rrBeta = max3(st.beta * bs.eta);
@@ -346,11 +439,11 @@ DMT_DEV void trace_pair_bvh(KArgs k, PathState const& st, bool doC, bool doS, ui
 
 // One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
 // sink(L, sidx) is called once per completed sample with the index the sample was started with.
-template <bool ENV = false, class Sink>
+template <bool ENV = false, bool AREA = false, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink);
 
-template <bool BVH, bool STATS = false, bool ENV = false, class Sink>
+template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, class Sink>
 DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneStats* ls = nullptr) {
   bool const doC = st.active;
   bool const doS = st.hasShadow;
@@ -362,11 +455,11 @@ DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneS
   else
     trace_pair_brute(k, st, doC, doS, bestTri, bu, bv, occluded);
   if constexpr (STATS) ls->bounces += (doC && bestTri >= 0 && st.depth < kargs(k)->maxDepth) ? 1u : 0u;
-  lane_finish<ENV>(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
+  lane_finish<ENV, AREA>(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
 }
 
 // Second half of a ray pass: resolve the shadow ray (in the reference's accumulation order), then shade.
-template <bool ENV, class Sink>
+template <bool ENV, bool AREA, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink) {
   if (doS) {
@@ -381,7 +474,7 @@ DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri
     }
   }
   if (doC) {
-    if (path_shade<ENV>(k, st, bestTri, bu, bv)) {
+    if (path_shade<ENV, AREA>(k, st, bestTri, bu, bv)) {
       st.active = false;
       if (st.hasShadow) {  // last NEE still untraced: park the sample, the lane may start the next
         put_Lfin(st.L);
@@ -723,7 +816,7 @@ DMT_DEV void flush_stats(KArgs Pk, LaneStats const& ls) {
   }
 }
 
-template <bool BVH, bool STATS = false, bool ENV = false>
+template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false>
 DMT_DEV void megakernel_body() {
   KArgs const Pk = kargs_base();
   LaneStats ls;
@@ -754,7 +847,7 @@ DMT_DEV void megakernel_body() {
           }
         }
       }
-      lane_step<BVH, STATS, ENV>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
+      lane_step<BVH, STATS, ENV, AREA>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
     }
   }
   flush_stats<STATS>(Pk, ls);
@@ -769,7 +862,7 @@ DMT_DEV void megakernel_body() {
 // shading runs for all waiting lanes at once when at least DMT_BVH_SHADE_THRESHOLD of them are waiting (or
 // nobody is traversing).  Incoherent rays take very different numbers of steps; with a pass-synchronous
 // loop the wave ran at 14 % lane utilisation.
-template <bool STATS = false, bool ENV = false>
+template <bool STATS = false, bool ENV = false, bool AREA = false>
 DMT_DEV void megakernel_body_bvh() {
   KArgs const Pk = kargs_base();
   LaneStats ls;
@@ -860,7 +953,7 @@ DMT_DEV void megakernel_body_bvh() {
       if constexpr (STATS) ++ls.itShade, ls.lanesShade += tv.phase == TR_DONE ? 1u : 0u;
       if (tv.phase == TR_DONE) {
         if constexpr (STATS) ls.bounces += (tv.doC && tv.bestTri >= 0 && st.depth < kargs(Pk)->maxDepth) ? 1u : 0u;
-        lane_finish<ENV>(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
+        lane_finish<ENV, AREA>(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
         tv.phase = TR_IDLE;
       }
     }
@@ -880,6 +973,9 @@ __global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats(RenderParams P)
 __global__ void __launch_bounds__(256, 3) k_megakernel_env(RenderParams P) { megakernel_body<false, false, true>(); }
 __global__ void __launch_bounds__(256, 2) k_megakernel_bvh_env(RenderParams P) { megakernel_body_bvh<false, true>(); }
 __global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats_env(RenderParams P) { megakernel_body_bvh<true, true>(); }
+// emissive triangles compiled in (dmt_upload_area_lights selects them)
+__global__ void __launch_bounds__(256, 3) k_megakernel_area(RenderParams P) { megakernel_body<false, false, false, true>(); }
+__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_area(RenderParams P) { megakernel_body_bvh<false, false, true>(); }
 
 // ---------------------------------------------------------------------------------------------
 // device unit-test kernels
@@ -898,7 +994,12 @@ __global__ void k_test_trace(RenderParams P, bool useBvh, int n, int32_t const* 
   for (;;) {
     if (!__any(st.active || st.hasShadow)) break;
     bool const useEnv = kargs(k)->env.w > 0;
-    if (useEnv) {
+    if (kargs(k)->areaCount > 0) {
+      if (useBvh)
+        lane_step<true, false, false, true>(k, gtid, st, store);
+      else
+        lane_step<false, false, false, true>(k, gtid, st, store);
+    } else if (useEnv) {
       if (useBvh)
         lane_step<true, false, true>(k, gtid, st, store);
       else
@@ -1121,6 +1222,13 @@ struct dmt_ctx {
   int blocksPerCUEnv = 0, blocksPerCUBvhEnv = 0;
   float* d_env = nullptr;  // A18: one allocation holding the five tables and the image
   EnvView env{};           // env.w == 0: no env map
+  int blocksPerCUArea = 0, blocksPerCUBvhArea = 0;
+  uint32_t* d_areaOf = nullptr;   // per-triangle area-light index
+  uint32_t* d_areaTri = nullptr;
+  float* d_areaLe = nullptr;
+  uint32_t areaCount = 0;
+  std::vector<uint32_t> h_areaTri;  // kept to rebuild areaOf when triangles are re-uploaded
+  std::vector<float> h_areaLe;
   bool haveTris = false, haveBsdfs = false, haveLights = false, haveCamera = false;
   // camera
   dmt_camera cam{};
@@ -1252,11 +1360,13 @@ RenderParams baseParams(dmt_ctx const* c, size_t threads) {
   P.sp = c->sp;
   P.maxDepth = c->maxDepth;
   P.env = c->env;
+  P.areaOf = c->d_areaOf, P.areaTri = c->d_areaTri, P.areaLe = c->d_areaLe, P.areaCount = c->areaCount;
   return P;
 }
 
 int blocksPerCuOf(dmt_ctx const* c) {
   bool const env = c->env.w > 0;
+  if (c->areaCount > 0) return c->accel == DMT_ACCEL_BVH ? c->blocksPerCUBvhArea : c->blocksPerCUArea;
   if (c->accel == DMT_ACCEL_BVH) return env ? c->blocksPerCUBvhEnv : c->blocksPerCUBvh;
   return env ? c->blocksPerCUEnv : c->blocksPerCU;
 }
@@ -1356,6 +1466,8 @@ int finishTest(dmt_ctx* ctx) {
 
 }  // namespace
 
+static int rebuildAreaLights(dmt_ctx* ctx);
+
 extern "C" {
 
 int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
@@ -1402,6 +1514,12 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
   ctx->blocksPerCUBvh = bpcBvh > 0 ? bpcBvh : 1;
   ctx->blocksPerCUEnv = bpcEnv > 0 ? bpcEnv : 1;
   ctx->blocksPerCUBvhEnv = bpcBvhEnv > 0 ? bpcBvhEnv : 1;
+  {
+    int a = 0, b = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<void const*>(k_megakernel_area), 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<void const*>(k_megakernel_bvh_area), 256, 0);
+    ctx->blocksPerCUArea = a > 0 ? a : 1, ctx->blocksPerCUBvhArea = b > 0 ? b : 1;
+  }
   if (char const* e2 = std::getenv("DMT_SUB_SHIFT")) {  // scheduling experiments only: results do not depend on it
     int const v = std::atoi(e2);
     ctx->subShift = v < 0 ? -1 : (v > 2 ? 2 : v);
@@ -1427,6 +1545,9 @@ int dmt_ctx_destroy(dmt_ctx* ctx) {
   (void)hipFree(ctx->d_tileDone);
   (void)hipFree(ctx->d_stage);
   (void)hipFree(ctx->d_env);
+  (void)hipFree(ctx->d_areaOf);
+  (void)hipFree(ctx->d_areaTri);
+  (void)hipFree(ctx->d_areaLe);
   (void)hipFree(ctx->d_bvhNodes);
   (void)hipFree(ctx->d_trisBvh);
   (void)hipFree(ctx->d_overflow);
@@ -1484,6 +1605,8 @@ int dmt_upload_triangles(dmt_ctx* ctx, const float* xs, const float* ys, const f
   ctx->h_xs.assign(xs, xs + 4 * count), ctx->h_ys.assign(ys, ys + 4 * count), ctx->h_zs.assign(zs, zs + 4 * count);
   ctx->h_mat.assign(mat_id, mat_id + count);
   ctx->haveBvh = false;
+  ctx->h_areaTri.clear(), ctx->h_areaLe.clear();  // emissive triangles are indices into the soup just replaced
+  if (int const rcA = rebuildAreaLights(ctx)) return rcA;
   if (ctx->accel == DMT_ACCEL_BVH) return buildBvh(ctx);
   return DMT_OK;
 }
@@ -1687,7 +1810,10 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   uint32_t const wavesWanted = P.numItems * P.numChunks < P.numItems ? P.numItems : P.numItems * P.numChunks;
   uint32_t blocks = uint32_t(ctx->cuCount) * uint32_t(blocksPerCuOf(ctx));
   bool const useEnv = ctx->env.w > 0;
+  bool const useArea = ctx->areaCount > 0;
+  if (useArea && useEnv) return fail(ctx, DMT_ERR_STATE, "dmt_render: emissive triangles and an env map cannot be combined yet");
   P.env = ctx->env;
+  P.areaOf = ctx->d_areaOf, P.areaTri = ctx->d_areaTri, P.areaLe = ctx->d_areaLe, P.areaCount = ctx->areaCount;
   uint32_t const blocksNeeded = (wavesWanted + 3) / 4;
   if (blocks > blocksNeeded) blocks = blocksNeeded;
   if (blocks == 0) blocks = 1;
@@ -1733,10 +1859,14 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
       HIP_TRY(ctx, e);
       return DMT_OK;
     }
-    if (useEnv)
+    if (useArea)
+      hipLaunchKernelGGL(k_megakernel_bvh_area, dim3(blocks), dim3(256), 0, ctx->stream, P);
+    else if (useEnv)
       hipLaunchKernelGGL(k_megakernel_bvh_env, dim3(blocks), dim3(256), 0, ctx->stream, P);
     else
       hipLaunchKernelGGL(k_megakernel_bvh, dim3(blocks), dim3(256), 0, ctx->stream, P);
+  } else if (useArea) {
+    hipLaunchKernelGGL(k_megakernel_area, dim3(blocks), dim3(256), 0, ctx->stream, P);
   } else if (useEnv) {
     hipLaunchKernelGGL(k_megakernel_env, dim3(blocks), dim3(256), 0, ctx->stream, P);
   } else {
@@ -1829,6 +1959,36 @@ int dmt_sync(dmt_ctx* ctx) {
     return fail(ctx, DMT_ERR_HIP, "a wave gave up waiting for a tile's previous sample chunk (in-launch ordering)");
   }
   return DMT_OK;
+}
+
+// (re)builds the per-triangle lookup from the host copy of the area-light list
+static int rebuildAreaLights(dmt_ctx* ctx) {
+  (void)hipFree(ctx->d_areaOf), (void)hipFree(ctx->d_areaTri), (void)hipFree(ctx->d_areaLe);
+  ctx->d_areaOf = nullptr, ctx->d_areaTri = nullptr, ctx->d_areaLe = nullptr, ctx->areaCount = 0;
+  uint32_t const n = uint32_t(ctx->h_areaTri.size());
+  if (n == 0 || !ctx->haveTris) return DMT_OK;
+  std::vector<uint32_t> of(ctx->triCount, 0xFFFFFFFFu);
+  for (uint32_t k = 0; k < n; ++k) {
+    if (ctx->h_areaTri[k] >= ctx->triCount) return fail(ctx, DMT_ERR_INVALID, "area light refers to a triangle outside the uploaded soup");
+    of[ctx->h_areaTri[k]] = k;
+  }
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_areaOf), of.size() * 4));
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_areaTri), size_t(n) * 4));
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_areaLe), size_t(n) * 12));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_areaOf, of.data(), of.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_areaTri, ctx->h_areaTri.data(), size_t(n) * 4, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_areaLe, ctx->h_areaLe.data(), size_t(n) * 12, hipMemcpyHostToDevice));
+  ctx->areaCount = n;
+  return DMT_OK;
+}
+
+int dmt_upload_area_lights(dmt_ctx* ctx, const uint32_t* triangle_index, const float* radiance_rgb, uint32_t count) {
+  if (!ctx || (count && (!triangle_index || !radiance_rgb))) return DMT_ERR_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->h_areaTri.assign(triangle_index, triangle_index + count);
+  ctx->h_areaLe.assign(radiance_rgb, radiance_rgb + 3 * size_t(count));
+  return rebuildAreaLights(ctx);
 }
 
 int dmt_envmap_tables(const float* rgb, int width, int height, float* func, float* cdf, float* row_integral,

@@ -1545,6 +1545,11 @@ struct Scene {
   Rec32 const* bsdfs;
   uint32_t bsdfCount;
   EnvMap const* env = nullptr;  // A18: replaces the constant environment when set
+  // emissive triangles (diffuse area lights).  areaOf[tri] = index into areaTri / areaLe or ~0u
+  uint32_t const* areaOf = nullptr;
+  uint32_t const* areaTri = nullptr;
+  float const* areaLe = nullptr;  // rgb per area light
+  uint32_t areaCount = 0;
 };
 
 struct Stats {  // algorithmic work counters (SURVEY 8d byte model)
@@ -1564,6 +1569,60 @@ inline uint32_t pickIndex(float u, uint32_t count) {
   uint32_t const a = uint32_t(int(u * float(count)));
   uint32_t const b = count - 1u;
   return a < b ? a : b;
+}
+
+// ---- emissive triangles (no reference implementation exists).  Semantics are pbrt-v4's, which the
+// reference's scenes/cornell-box.pbrt is written for: DiffuseAreaLight, one-sided on the side of
+// n = normalize(cross(p1 - p0, p2 - p0)); uniform point sampling (SampleUniformTriangle); light chosen uniformly among
+// [point/spot lights..., emissive triangles...]; power-heuristic MIS between light and BSDF sampling; emission seen
+// directly by camera rays and after delta bounces.
+struct AreaSample {
+  V3 wi;
+  float dist, pdf;  // solid-angle pdf
+  bool ok;
+};
+inline void areaTriangle(Scene const& sc, uint32_t tri, V3& p0, V3& p1, V3& p2) {
+  float const *x = sc.xs + 4 * size_t(tri), *y = sc.ys + 4 * size_t(tri), *z = sc.zs + 4 * size_t(tri);
+  p0 = v3(x[0], y[0], z[0]), p1 = v3(x[1], y[1], z[1]), p2 = v3(x[2], y[2], z[2]);
+}
+inline AreaSample areaSample(Scene const& sc, uint32_t tri, V3 p, V2 u) {
+  AreaSample r{};
+  V3 p0, p1, p2;
+  areaTriangle(sc, tri, p0, p1, p2);
+  float b0, b1;
+  if (u.x < u.y) {
+    b0 = u.x / 2;
+    b1 = u.y - b0;
+  } else {
+    b1 = u.y / 2;
+    b0 = u.x - b1;
+  }
+  V3 const q = b0 * p0 + b1 * p1 + (1 - b0 - b1) * p2;
+  V3 const c = cross(p1 - p0, p2 - p0);
+  float const len = sqrtf(dot(c, c));
+  if (!(len > 0.f)) return r;
+  V3 const n = c / len;
+  V3 const d = q - p;
+  float const d2 = dot(d, d);
+  if (!(d2 > 0.f)) return r;
+  r.dist = sqrtf(d2);
+  r.wi = d / r.dist;
+  float const cosL = -dot(n, r.wi);
+  if (!(cosL > 0.f)) return r;  // one-sided
+  r.pdf = d2 / (cosL * (0.5f * len));
+  r.ok = true;
+  return r;
+}
+// pdf (solid angle) of having sampled the point a ray hits on emissive triangle `tri`; 0 when seen from behind
+inline float areaPdf(Scene const& sc, uint32_t tri, V3 rayD, float t) {
+  V3 p0, p1, p2;
+  areaTriangle(sc, tri, p0, p1, p2);
+  V3 const c = cross(p1 - p0, p2 - p0);
+  float const len = sqrtf(dot(c, c));
+  if (!(len > 0.f)) return 0.f;
+  float const cosL = -dot(c / len, rayD);
+  if (!(cosL > 0.f)) return 0.f;
+  return (t * t) / (cosL * (0.5f * len));
 }
 
 // one path; returns radiance L                                      megakernel.cu:103-297
@@ -1626,6 +1685,18 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
       }
       break;
     }
+    if (sc.areaCount > 0 && sc.areaOf[hitTri] != 0xFFFFFFFFu) {  // emitted radiance of the surface the path ray hit
+      float const pl = areaPdf(sc, uint32_t(hitTri), ray.d, hit.t);
+      if (pl > 0.f) {
+        V3 const Le = v3(sc.areaLe[3 * sc.areaOf[hitTri]], sc.areaLe[3 * sc.areaOf[hitTri] + 1], sc.areaLe[3 * sc.areaOf[hitTri] + 2]);
+        if (depth == 0 || specularBounce) {
+          L += beta * Le;
+        } else {
+          float const a = lastBsdfPdf, b = pl / float(sc.lightCount + sc.areaCount);
+          L += beta * Le * ((a * a) / (a * a + b * b));
+        }
+      }
+    }
     if (depth >= cfg.maxDepth) break;
     if (st) st->bounces++, st->hits++;
     bsdf = sc.bsdfs[hit.matId];
@@ -1638,7 +1709,40 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
       envNee = uLight < 0.5f;
       uLight = envNee ? uLight : (uLight - 0.5f) * 2.f;
     }
-    if (envNee) {
+    bool areaNee = false;
+    uint32_t areaIdx = 0;
+    if (sc.areaCount > 0) {  // uniform choice among point/spot lights and emissive triangles
+      uint32_t const li = pickIndex(uLight, sc.lightCount + sc.areaCount);
+      areaNee = li >= sc.lightCount;
+      areaIdx = areaNee ? li - sc.lightCount : 0u;
+    }
+    if (areaNee) {
+      uint32_t const tri = sc.areaTri[areaIdx];
+      AreaSample const as = areaSample(sc, tri, hit.pos, uLight2);
+      if (as.ok) {
+        Ray const shadow{offsetRayOrigin(hit.pos, hit.error, hit.normal, as.wi), as.wi};
+        float const smax = as.dist * 0.999f;
+        bool visible = true;
+        if (st) st->shadowRays++;
+        for (uint64_t t2 = 0; t2 < sc.triCount; ++t2) {
+          if (st) st->triTests++;
+          Hit const r = triangleIntersect(sc.xs + 4 * t2, sc.ys + 4 * t2, sc.zs + 4 * t2, shadow);
+          if (r.hit && r.t < smax) {
+            visible = false;
+            break;
+          }
+        }
+        if (visible) {
+          float bsdfPdf = 0;
+          V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, hit.normal, hit.normal, &bsdfPdf) * bsdfWeight(bsdf);
+          if (!isZero(f)) {
+            V3 const Le = v3(sc.areaLe[3 * areaIdx], sc.areaLe[3 * areaIdx + 1], sc.areaLe[3 * areaIdx + 2]);
+            float const a = as.pdf / float(sc.lightCount + sc.areaCount), b = bsdfPdf;
+            L += beta * (Le * f * (((a * a) / (a * a + b * b)) / a));
+          }
+        }
+      }
+    } else if (envNee) {
       EnvSample const es = envSample(*sc.env, uLight2);
       if (es.ok) {
         Ray const shadow{offsetRayOrigin(hit.pos, hit.error, hit.normal, es.wi), es.wi};
@@ -1660,9 +1764,9 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
         }
       }
     } else if (sc.lightCount > 0) {
-      uint32_t const li = pickIndex(uLight, sc.lightCount);
+      uint32_t const li = sc.areaCount > 0 ? pickIndex(uLight, sc.lightCount + sc.areaCount) : pickIndex(uLight, sc.lightCount);
       Rec32 const& light = sc.lights[li];
-      float const lightPMF = (sc.env ? 0.5f : 1.f) / sc.lightCount;
+      float const lightPMF = (sc.env ? 0.5f : 1.f) / float(sc.lightCount + sc.areaCount);
       LightSample const ls = sampleLight(light, hit.pos, uLight2, lastBounceTransmission, hit.normal);
       if (ls.valid()) {
         Ray const shadow{offsetRayOrigin(hit.pos, hit.error, hit.normal, ls.direction), ls.direction};
@@ -1893,10 +1997,20 @@ struct OracleScene {  // mirrors include/dmt_hip.h's upload calls
   int32_t envW, envH;
   float envQuat[4];
   float envScale;
+  // emissive triangles -- triangle indices and rgb radiance per entry
+  const uint32_t* areaTri;
+  const float* areaLe;
+  uint32_t areaCount;
 };
 
-static Scene toScene(OracleScene const* s, EnvMap* envStorage = nullptr) {
+static Scene toScene(OracleScene const* s, EnvMap* envStorage = nullptr, std::vector<uint32_t>* areaStorage = nullptr) {
   Scene sc;
+  if (areaStorage && s->areaCount > 0 && s->areaTri && s->areaLe) {
+    areaStorage->assign(size_t(s->triCount), 0xFFFFFFFFu);
+    for (uint32_t k = 0; k < s->areaCount; ++k)
+      if (s->areaTri[k] < s->triCount) (*areaStorage)[s->areaTri[k]] = k;
+    sc.areaOf = areaStorage->data(), sc.areaTri = s->areaTri, sc.areaLe = s->areaLe, sc.areaCount = s->areaCount;
+  }
   if (envStorage && s->envRgb && s->envW > 0 && s->envH > 0) {
     envBuild(s->envRgb, s->envW, s->envH, s->envQuat, s->envScale, *envStorage);
     sc.env = envStorage;
@@ -2127,7 +2241,8 @@ int oracle_render(const OracleScene* s, const void* camera44, int maxDepth, int 
   Camera cam;
   memcpy(&cam, camera44, sizeof(Camera));
   EnvMap env;
-  Scene const sc = toScene(s, &env);
+  std::vector<uint32_t> areaOf;
+  Scene const sc = toScene(s, &env, &areaOf);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   if (x0 < 0) x0 = 0;
   if (y0 < 0) y0 = 0;
@@ -2177,7 +2292,8 @@ void oracle_trace_samples(const OracleScene* s, const void* camera44, int maxDep
   Camera cam;
   memcpy(&cam, camera44, sizeof(Camera));
   EnvMap env;
-  Scene const sc = toScene(s, &env);
+  std::vector<uint32_t> areaOf;
+  Scene const sc = toScene(s, &env, &areaOf);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   for (int i = 0; i < n; ++i) {
     V3 const L = tracePath(sc, cfg, pxs[i], pys[i], ss[i], nullptr);
@@ -2191,7 +2307,8 @@ int oracle_trace_log(const OracleScene* s, const void* camera44, int maxDepth, i
   Camera cam;
   memcpy(&cam, camera44, sizeof(Camera));
   EnvMap env;
-  Scene const sc = toScene(s, &env);
+  std::vector<uint32_t> areaOf;
+  Scene const sc = toScene(s, &env, &areaOf);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   PathLog log;
   log.rec = rec12, log.cap = cap;

@@ -29,6 +29,7 @@ class OracleScene(C.Structure):
         ("bsdfs", C.c_void_p), ("bsdfCount", C.c_uint32),
         ("envRgb", C.c_void_p), ("envW", C.c_int32), ("envH", C.c_int32), ("envQuat", C.c_float * 4),
         ("envScale", C.c_float),
+        ("areaTri", C.c_void_p), ("areaLe", C.c_void_p), ("areaCount", C.c_uint32),
     ]
 
 
@@ -76,6 +77,14 @@ class Scene:
         self.env_rgb = None            # A18: optional env map, float32 [h, w, 3], w == 2 h, powers of two
         self.env_quat = np.array([0, 0, 0, 1], np.float32)  # lightFromRender, x y z w
         self.env_scale = 1.0
+        self.area_tri, self.area_le = None, None
+
+    def set_area_lights(self, tri, le):
+        """emissive triangles (indices into the triangle arrays) and their rgb radiance."""
+        self.area_tri = np.ascontiguousarray(tri, np.uint32).reshape(-1)
+        self.area_le = np.ascontiguousarray(le, np.float32).reshape(-1, 3)
+        assert self.area_tri.shape[0] == self.area_le.shape[0]
+        return self
 
     def set_envmap(self, rgb, quat=(0, 0, 0, 1), scale=1.0):
         rgb = np.ascontiguousarray(rgb, np.float32)
@@ -112,6 +121,8 @@ class Scene:
             s.envRgb, s.envH, s.envW = _p(self.env_rgb), self.env_rgb.shape[0], self.env_rgb.shape[1]
             s.envQuat = (C.c_float * 4)(*[float(v) for v in self.env_quat])
             s.envScale = self.env_scale
+        if self.area_tri is not None and self.area_tri.shape[0] > 0:
+            s.areaTri, s.areaLe, s.areaCount = _p(self.area_tri), _p(self.area_le), self.area_tri.shape[0]
         return s
 
 

@@ -698,3 +698,50 @@ def test_sphere_envmap_workload_scene(renderer, pkg, O):
     scale = float(om[..., :3].mean())
     assert scale > 0.2
     assert float(np.sqrt(np.mean((mean[..., :3] - om[..., :3]) ** 2))) < 2e-3 * scale
+
+
+# ---------------------------------------------------------------------------------------------
+# emissive triangles (diffuse area lights, pbrt-v4 semantics).  No reference implementation: parity is
+# oracle <-> HIP only.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("accel", [0, 1])
+def test_area_lights_film_vs_oracle(renderer, O, accel):
+    sc = O.cornell_box(56, 56)
+    # no point/spot lights: light the box with two of its own triangles (both facings occur in the soup)
+    sc.lights = sc.lights[:0]
+    emit = [0, 1, 16, 17, 20, 21]
+    # emission is one-sided on normalize(cross(p1 - p0, p2 - p0)) (pbrt's convention), which for the reference's
+    # generators points out of the room: rewind four of the emitters so that both facings are exercised
+    for a in (sc.xs, sc.ys, sc.zs):
+        a[[0, 1, 16, 17]] = a[[0, 1, 16, 17]][:, [0, 2, 1, 3]]
+    sc.set_area_lights(emit, [[6, 6, 5], [6, 6, 5], [12, 14, 20], [12, 14, 20], [20, 15, 10], [20, 15, 10]])
+    renderer.upload_scene(sc)
+    renderer.set_limits(6)
+    renderer.set_accel(accel)
+    renderer.set_partition(0, 1)
+    try:
+        renderer.film_clear()
+        renderer.render(32)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
+    finally:
+        renderer.set_accel(0)
+        renderer.upload_area_lights([], np.zeros((0, 3), np.float32))
+    om, om2 = O.render(sc, 32, max_depth=6, threads=8)[:2]
+    assert np.array_equal(m2[..., 3], om2[..., 3])
+    scale = float(om[..., :3].mean())
+    plain = O.render(O.cornell_box(56, 56), 4, max_depth=6, threads=8)[0]
+    assert scale > 0.2 and abs(scale - float(plain[..., :3].mean())) > 0.1   # the emitters light the room
+    assert float(np.sqrt(np.mean((mean[..., :3] - om[..., :3]) ** 2))) < 1e-3 * max(1.0, scale)
+
+
+def test_area_lights_are_cleared_by_a_new_soup(renderer, O):
+    sc = O.cornell_box(32, 32)
+    sc.set_area_lights([0], [[5, 5, 5]])
+    renderer.upload_scene(sc)
+    plain = O.cornell_box(32, 32)
+    renderer.upload_scene(plain)                          # new triangles: the emissive list must not survive
+    renderer.set_limits(4); renderer.film_clear(); renderer.render(4); renderer.sync()
+    a = renderer.download_film()
+    om = O.render(plain, 4, max_depth=4, threads=4)[0]
+    assert float(np.sqrt(np.mean((a[0][..., :3] - om[..., :3]) ** 2))) < 1e-4
