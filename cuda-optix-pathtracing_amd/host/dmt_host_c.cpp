@@ -62,6 +62,29 @@ int64_t dmt_host_read_fbx(const char* path, float* out9, uint64_t cap_triangles,
     }
   return int64_t(tris.size());
 }
+// PBRT-v4 subset front-end; same protocol as dmt_host_scene_load_json
+dmt_host_scene* dmt_host_scene_load_pbrt(const char* path, int* max_depth, int* samples_per_pixel, char* err, uint64_t err_cap) {
+  auto* h = new (std::nothrow) dmt_host_scene();
+  if (!h || !path) return delete h, nullptr;
+  PbrtScene ps;
+  std::string msg;
+  if (!loadPbrtScene(path, ps, &msg)) {
+    if (err && err_cap) {
+      size_t const n = msg.size() < err_cap - 1 ? msg.size() : size_t(err_cap - 1);
+      memcpy(err, msg.data(), n);
+      err[n] = 0;
+    }
+    delete h;
+    return nullptr;
+  }
+  h->s = std::move(ps.scene);
+  if (max_depth) *max_depth = ps.maxDepth;
+  if (samples_per_pixel) *samples_per_pixel = ps.samplesPerPixel;
+  return h;
+}
+uint32_t dmt_host_scene_area_light_count(const dmt_host_scene* h) { return uint32_t(h->s.areaTri.size()); }
+const uint32_t* dmt_host_scene_area_tri(const dmt_host_scene* h) { return h->s.areaTri.data(); }
+const float* dmt_host_scene_area_le(const dmt_host_scene* h) { return h->s.areaLe.data(); }
 const float* dmt_host_scene_env_rgb(const dmt_host_scene* h, int* width, int* height) {
   if (width) *width = h->s.envWidth;
   if (height) *height = h->s.envHeight;

@@ -397,6 +397,8 @@ int uploadScene(dmt_ctx* ctx, Scene const& s) {
   if (rc) return rc;
   rc = dmt_set_camera(ctx, &s.camera);
   if (rc) return rc;
+  rc = dmt_upload_area_lights(ctx, s.areaTri.data(), s.areaLe.data(), uint32_t(s.areaTri.size()));
+  if (rc) return rc;
   if (!s.envRgb.empty()) return dmt_upload_envmap(ctx, s.envRgb.data(), s.envWidth, s.envHeight, s.envQuat, s.envScale);
   return dmt_clear_envmap(ctx);
 }

@@ -64,6 +64,10 @@ struct Scene {
   int envWidth = 0, envHeight = 0;
   float envQuat[4] = {0.f, 0.f, 0.f, 1.f};  // lightFromRender, x y z w
   float envScale = 1.f;
+  // optional emissive triangles (the PBRT front-end's AreaLightSource): indices into the arrays above
+  // and rgb radiance per entry
+  std::vector<uint32_t> areaTri;
+  std::vector<float> areaLe;
 
   size_t triangleCount() const { return matId.size(); }
   // addModel + the material walk of triSoupFromTriangles: the FIRST mesh always gets material 0
@@ -92,6 +96,15 @@ struct JsonScene {
   int samplesPerPixel = 1;   // film "samples"   (core-types.h:28)
 };
 bool loadJsonScene(std::string const& path, JsonScene& out, std::string* error = nullptr);
+// PBRT-v4 subset front-end (scenes/cornell-box.pbrt): Film, Sampler, LookAt, Camera "perspective",
+// Attribute blocks, Translate / Rotate / Scale / Transform, named "diffuse" materials, "trianglemesh" shapes and
+// "diffuse" area lights (host/dmt_pbrt_scene.cpp)
+struct PbrtScene {
+  Scene scene;
+  int maxDepth = 5;         // pbrt's PathIntegrator default
+  int samplesPerPixel = 16;  // pbrt's sampler default
+};
+bool loadPbrtScene(std::string const& path, PbrtScene& out, std::string* error = nullptr);
 // binary FBX (Kaydara 7100+): first mesh, fan-triangulated, Model TRS and unit scale applied (host/dmt_fbx.cpp)
 bool readFbxMesh(std::string const& path, std::vector<Triangle>& out, std::string* error = nullptr);
 // 8-bit grey / RGB / RGBA non-interlaced PNG -> RGB floats, byte / 255 as the reference's loadImageAsRGB

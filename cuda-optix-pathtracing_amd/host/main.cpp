@@ -50,7 +50,8 @@ void printHelp() {
       "  --max-depth <N>   -- Bounce cap (reference: 32)\n"
       "  --device <N>      -- GPU ordinal\n"
       "  --out <dir>       -- Output directory (default: the executable's directory)\n"
-      "  --scene <file>    -- JSON scene (camera/film/materials/objects/lights/envlight/transforms/world);\n"
+      "  --scene <file>    -- JSON scene (camera/film/materials/objects/lights/envlight/transforms/world) or *.pbrt\n"
+      "                       (PBRT-v4 subset: diffuse materials, triangle meshes, diffuse area lights);\n"
       "                       its resolution, samples and max-depth apply unless given on the command line\n"
       "  --bvh             -- BVH traversal instead of the brute-force triangle loop");
 }
@@ -99,7 +100,16 @@ int main(int argc, char** argv) {
   dmt_host::JsonScene json;
   if (!cfg.scenePath.empty()) {
     std::string err;
-    if (!dmt_host::loadJsonScene(cfg.scenePath, json, &err)) {
+    bool const pbrt = cfg.scenePath.size() > 5 && cfg.scenePath.compare(cfg.scenePath.size() - 5, 5, ".pbrt") == 0;
+    bool ok;
+    if (pbrt) {  // PBRT-v4 subset (scenes/cornell-box.pbrt); same fields as the JSON front-end
+      dmt_host::PbrtScene ps;
+      ok = dmt_host::loadPbrtScene(cfg.scenePath, ps, &err);
+      json.scene = std::move(ps.scene), json.maxDepth = ps.maxDepth, json.samplesPerPixel = ps.samplesPerPixel;
+    } else {
+      ok = dmt_host::loadJsonScene(cfg.scenePath, json, &err);
+    }
+    if (!ok) {
       std::fprintf(stderr, "scene '%s': %s\n", cfg.scenePath.c_str(), err.c_str());
       return 1;
     }

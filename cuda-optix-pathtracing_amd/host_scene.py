@@ -19,7 +19,8 @@ def load_host_library():
         for name in ("dmt_host_scene_cornell_box", "dmt_host_scene_random_triangles", "dmt_host_scene_xs",
                      "dmt_host_scene_ys", "dmt_host_scene_zs", "dmt_host_scene_mat_ids", "dmt_host_scene_bsdfs",
                      "dmt_host_scene_lights", "dmt_host_scene_infinite_lights", "dmt_host_scene_camera",
-                     "dmt_host_scene_load_json", "dmt_host_scene_env_rgb"):
+                     "dmt_host_scene_load_json", "dmt_host_scene_env_rgb", "dmt_host_scene_load_pbrt",
+                     "dmt_host_scene_area_tri", "dmt_host_scene_area_le"):
             getattr(lib, name).restype = C.c_void_p
         lib.dmt_host_scene_random_triangles.argtypes = [C.c_uint64, C.c_uint64]
         lib.dmt_host_scene_triangle_count.restype = C.c_uint64
@@ -62,6 +63,10 @@ class HostScene:
         self.env_rgb = _copy(env, np.float32, 3 * ew.value * eh.value).reshape(eh.value, ew.value, 3) if env else None
         self.env_quat, self.env_scale = np.array([0, 0, 0, 1], np.float32), 1.0
         self.max_depth, self.spp = None, None
+        L.dmt_host_scene_area_light_count.restype = C.c_uint32
+        na = L.dmt_host_scene_area_light_count(h)
+        self.area_tri = _copy(L.dmt_host_scene_area_tri(h), np.uint32, na)
+        self.area_le = _copy(L.dmt_host_scene_area_le(h), np.float32, 3 * na).reshape(-1, 3)
         L.dmt_host_scene_destroy(h)
 
     @property
@@ -103,6 +108,19 @@ def load_json(path):
     h = L.dmt_host_scene_load_json(str(path).encode(), C.byref(md), C.byref(spp), err, C.c_uint64(len(err)))
     if not h:
         raise ValueError(err.value.decode() or "dmt_host_scene_load_json failed")
+    s = HostScene(h)
+    s.max_depth, s.spp = md.value, spp.value
+    return s
+
+
+def load_pbrt(path):
+    """PBRT-v4 subset (scenes/cornell-box.pbrt's directives) -> HostScene (+ .max_depth, .spp, .area_tri, .area_le)."""
+    L = load_host_library()
+    md, spp = C.c_int(), C.c_int()
+    err = C.create_string_buffer(1024)
+    h = L.dmt_host_scene_load_pbrt(str(path).encode(), C.byref(md), C.byref(spp), err, C.c_uint64(len(err)))
+    if not h:
+        raise ValueError(err.value.decode() or "dmt_host_scene_load_pbrt failed")
     s = HostScene(h)
     s.max_depth, s.spp = md.value, spp.value
     return s

@@ -745,3 +745,44 @@ def test_area_lights_are_cleared_by_a_new_soup(renderer, O):
     a = renderer.download_film()
     om = O.render(plain, 4, max_depth=4, threads=4)[0]
     assert float(np.sqrt(np.mean((a[0][..., :3] - om[..., :3]) ** 2))) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# PBRT-v4 subset end to end: file -> loader -> HIP render, checked against the oracle (tight) and
+# against pbrt's OWN rendering of the same scene (scenes/pbrt-output.png of the reference, kept as a golden image;
+# sRGB 8-bit, spectral renderer: supports a coarse claim only)
+# ---------------------------------------------------------------------------------------------
+def test_pbrt_cornell_box_vs_oracle_and_pbrt_image(renderer, pkg, O):
+    from PIL import Image
+    hs = pkg.host_scene.load_pbrt(GOLDEN / "pbrt" / "cornell_box.pbrt")
+    renderer.upload_scene(hs)
+    renderer.set_limits(hs.max_depth)
+    renderer.set_accel(1)
+    renderer.set_partition(0, 1)
+    try:
+        renderer.film_clear()
+        renderer.render(256)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
+        # oracle on a band of rows, same samples
+        osc = O.Scene(hs.xs, hs.ys, hs.zs, hs.mat_id, hs.bsdfs, hs.lights, hs.inf_lights, hs.camera)
+        osc.set_area_lights(hs.area_tri, hs.area_le)
+        renderer.film_clear()
+        renderer.render(16, region=(0, 120, 256, 136))
+        renderer.sync()
+        band = renderer.download_film()[0][120:136, :, :3]
+    finally:
+        renderer.set_accel(0)
+        renderer.upload_area_lights([], np.zeros((0, 3), np.float32))
+    om = O.render(osc, 16, max_depth=hs.max_depth, region=(0, 120, 256, 136), threads=8)[0][120:136, :, :3]
+    assert float(np.sqrt(np.mean((band - om) ** 2))) < 1e-3 * max(1.0, float(om.mean()))
+
+    lin = np.clip(mean[..., :3], 0, 1)
+    srgb = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(lin, 1 / 2.4) - 0.055)
+    img = np.clip(srgb * 255 + 0.5, 0, 255)
+    ref = np.asarray(Image.open(GOLDEN / "pbrt" / "pbrt_output_reference.png"))[..., :3].astype(np.float64)
+    mad = float(np.abs(img - ref).mean())
+    mad_mirrored = float(np.abs(img[:, ::-1] - ref).mean())
+    assert mad < 16.0 and mad_mirrored > 2.5 * mad, (mad, mad_mirrored)     # same picture, same orientation
+    g1, g2 = img.mean(axis=2).ravel(), ref.mean(axis=2).ravel()
+    assert float(np.corrcoef(g1, g2)[0, 1]) > 0.9
