@@ -116,45 +116,52 @@ struct Builder {
     uint32_t mid = first + count / 2;
     bool const mustBalance = ceilLog2((count + kBvhMaxLeafTris - 1) / kBvhMaxLeafTris) >= depthBudget;
     bool split = false;
-    if (!mustBalance && ext > 0.f) {  // binned SAH on the longest centroid axis
+    if (!mustBalance && ext > 0.f) {  // binned SAH, best of the three axes
       constexpr int B = 16;
-      Box bb[B];
-      uint32_t bc[B] = {};
-      for (auto& b : bb) b.reset();
-      float const k = float(B) * (1.f - 1e-6f) / ext;
-      auto binOf = [&](uint32_t t) {
-        int b = int((centroid[3 * t + axis] - cbox.lo[axis]) * k);
-        return b < 0 ? 0 : (b >= B ? B - 1 : b);
-      };
-      for (uint32_t i = first; i < first + count; ++i) {
-        int const b = binOf(order[i]);
-        bb[b].grow(triBox[order[i]]);
-        ++bc[b];
-      }
-      float rightArea[B];
-      uint32_t rightCnt[B];
-      Box acc;
-      acc.reset();
-      uint32_t c = 0;
-      for (int b = B - 1; b > 0; --b) {
-        acc.grow(bb[b]);
-        c += bc[b];
-        rightArea[b] = acc.area(), rightCnt[b] = c;
-      }
-      acc.reset();
-      c = 0;
       float bestCost = std::numeric_limits<float>::infinity();
-      int bestSplit = -1;
-      for (int b = 0; b < B - 1; ++b) {
-        acc.grow(bb[b]);
-        c += bc[b];
-        if (c == 0 || rightCnt[b + 1] == 0) continue;
-        float const cost = acc.area() * float(c) + rightArea[b + 1] * float(rightCnt[b + 1]);
-        if (cost < bestCost) bestCost = cost, bestSplit = b;
+      int bestSplit = -1, bestAxis = -1;
+      float bestK = 0.f;
+      for (int ax = 0; ax < 3; ++ax) {
+        float const e = cbox.hi[ax] - cbox.lo[ax];
+        if (!(e > 0.f)) continue;
+        Box bb[B];
+        uint32_t bc[B] = {};
+        for (auto& b : bb) b.reset();
+        float const k = float(B) * (1.f - 1e-6f) / e;
+        for (uint32_t i = first; i < first + count; ++i) {
+          int b = int((centroid[3 * order[i] + ax] - cbox.lo[ax]) * k);
+          b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+          bb[b].grow(triBox[order[i]]);
+          ++bc[b];
+        }
+        float rightArea[B];
+        uint32_t rightCnt[B];
+        Box acc;
+        acc.reset();
+        uint32_t c = 0;
+        for (int b = B - 1; b > 0; --b) {
+          acc.grow(bb[b]);
+          c += bc[b];
+          rightArea[b] = acc.area(), rightCnt[b] = c;
+        }
+        acc.reset();
+        c = 0;
+        for (int b = 0; b < B - 1; ++b) {
+          acc.grow(bb[b]);
+          c += bc[b];
+          if (c == 0 || rightCnt[b + 1] == 0) continue;
+          float const cost = acc.area() * float(c) + rightArea[b + 1] * float(rightCnt[b + 1]);
+          if (cost < bestCost) bestCost = cost, bestSplit = b, bestAxis = ax, bestK = k;
+        }
       }
       if (bestSplit >= 0) {
-        auto it = std::partition(order.begin() + first, order.begin() + first + count,
-                                 [&](uint32_t t) { return binOf(t) <= bestSplit; });
+        int const ax = bestAxis;
+        float const lo = cbox.lo[ax];
+        auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+          int b = int((centroid[3 * t + ax] - lo) * bestK);
+          b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+          return b <= bestSplit;
+        });
         mid = uint32_t(it - order.begin());
         split = mid > first && mid < first + count;
       }
