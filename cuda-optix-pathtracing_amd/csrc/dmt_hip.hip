@@ -970,12 +970,12 @@ __global__ void __launch_bounds__(256, DMT_MIN_WAVES_PER_SIMD_BVH) k_megakernel_
 __global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats(RenderParams P) { megakernel_body_bvh<true>(); }
 // A18: the same two kernels with the env-map light compiled in (dmt_upload_envmap selects them).  Separate
 // instantiations, so that the register allocation of the default kernels is not touched.
-__global__ void __launch_bounds__(256, 3) k_megakernel_env(RenderParams P) { megakernel_body<false, false, true>(); }
-__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_env(RenderParams P) { megakernel_body_bvh<false, true>(); }
+__global__ void __launch_bounds__(256, 4) k_megakernel_env(RenderParams P) { megakernel_body<false, false, true>(); }
+__global__ void __launch_bounds__(256, 3) k_megakernel_bvh_env(RenderParams P) { megakernel_body_bvh<false, true>(); }
 __global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats_env(RenderParams P) { megakernel_body_bvh<true, true>(); }
 // emissive triangles compiled in (dmt_upload_area_lights selects them)
-__global__ void __launch_bounds__(256, 3) k_megakernel_area(RenderParams P) { megakernel_body<false, false, false, true>(); }
-__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_area(RenderParams P) { megakernel_body_bvh<false, false, true>(); }
+__global__ void __launch_bounds__(256, 4) k_megakernel_area(RenderParams P) { megakernel_body<false, false, false, true>(); }
+__global__ void __launch_bounds__(256, 3) k_megakernel_bvh_area(RenderParams P) { megakernel_body_bvh<false, false, true>(); }
 
 // ---------------------------------------------------------------------------------------------
 // device unit-test kernels
