@@ -4,7 +4,7 @@
 // free: consecutive lanes hit consecutive banks); deeper entries -- rare -- go to a per-lane column of
 // a global overflow array.  A node is seven 16-byte per-lane loads (boxes as SoA + child refs), the
 // four slab tests are plain VALU min/max, hit children are ordered by a 5-exchange network and the
-// nearest is entered directly (no push/pop).  Leaves hold <= 4 triangles, contiguous in traversal
+// nearest is entered directly (no push/pop).  Leaves hold <= 2 triangles (one pair), in traversal
 // order, tested with the SAME Moeller-Trumbore core as the brute-force loop, so the closest hit
 // (t,u,v and triangle, lowest original index on ties) is bit-identical to brute force.
 #pragma once
@@ -290,7 +290,7 @@ template <bool STATS = false>
 DMT_DEV void trav_leaf(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
   bool const closest = tv.phase == TR_CLOSEST;
   uint32_t const first = tv.cur & 0x0FFFFFFFu;
-  uint32_t const cnt = ((tv.cur >> 28) & 7u) + 1u;
+  uint32_t const cnt = kBvhMaxLeafTris <= 2 ? 1u : ((tv.cur >> 28) & 7u) + 1u;  // builder's leaf size: one pair
   for (uint32_t j = 0; j < cnt; ++j) {
     PairHit const h = pair_test(bv.pairs[first + j], tv.o, tv.d);
     if constexpr (STATS) tc->tris += h.orig0 != h.orig1 ? 2u : 1u;  // an odd leaf repeats its last triangle
