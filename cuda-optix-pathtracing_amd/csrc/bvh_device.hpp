@@ -97,6 +97,7 @@ DMT_DEV PairHit pair_test(TriPair const& P, f3 o, f3 d) {
 
 struct TraversalCounters {  // per-lane work counters (stats build of the kernel only)
   uint32_t nodes = 0, tris = 0;
+  uint32_t deadNodes = 0;  // visited nodes none of whose children was entered or pushed
 };
 
 // closest hit: bestTri = ORIGINAL triangle index or -1
@@ -266,6 +267,7 @@ DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc =
   cswap(k1, r1, k3, r3);
   cswap(k1, r1, k2, r2);
   bool const p3 = k3 < kInf, p2 = k2 < kInf, p1 = k1 < kInf, p0 = k0 < kInf;
+  if constexpr (STATS) tc->deadNodes += p0 ? 0u : 1u;
   if (!__any(tv.stack.sp > kBvhLdsStack - 3)) {
     // whole wave within the LDS part of the stack: branch-free.  All three candidates are written, far to
     // near, each at the slot the previous one left free if it was a miss; slots above the new top are dead.

@@ -813,6 +813,7 @@ DMT_DEV void flush_stats(KArgs Pk, LaneStats const& ls) {
     atomicAdd(&stats[11], (unsigned long long)ls.lanesLeaf);
     atomicAdd(&stats[12], (unsigned long long)ls.lanesShade);
     atomicAdd(&stats[13], (unsigned long long)ls.lanesPrep);
+    atomicAdd(&stats[14], (unsigned long long)ls.tc.deadNodes);
   }
 }
 

@@ -140,7 +140,7 @@ int dmt_render_stats(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0,
                      uint64_t* stats6);
 /* Diagnostic: dmt_render_stats plus the loop profile of the BVH kernel.  stats16 = the six counters above, then
  * wave-loop iterations x 64 (node steps, leaf steps, shading steps, outer iterations, sample preparations) and the
- * lanes that did work in leaf / shading / preparation steps; two reserved words. */
+ * lanes that did work in leaf / shading / preparation steps; node visits that entered no child; one reserved word. */
 int dmt_render_profile(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1,
                        uint64_t* stats16);
 int dmt_sync(dmt_ctx* ctx);
