@@ -786,3 +786,18 @@ def test_pbrt_cornell_box_vs_oracle_and_pbrt_image(renderer, pkg, O):
     assert mad < 16.0 and mad_mirrored > 2.5 * mad, (mad, mad_mirrored)     # same picture, same orientation
     g1, g2 = img.mean(axis=2).ravel(), ref.mean(axis=2).ravel()
     assert float(np.corrcoef(g1, g2)[0, 1]) > 0.9
+
+
+def test_env_map_and_area_lights_are_mutually_exclusive_for_now(renderer, pkg, O):
+    sc = O.cornell_box(32, 32)
+    sc.set_area_lights([0], [[1, 1, 1]])
+    renderer.upload_scene(sc)
+    renderer.upload_envmap(np.ones((8, 16, 3), np.float32))
+    try:
+        with pytest.raises(pkg.DmtError, match="cannot be combined"):
+            renderer.render(1)
+    finally:
+        renderer.clear_envmap()
+        renderer.upload_area_lights([], np.zeros((0, 3), np.float32))
+    renderer.render(1)
+    renderer.sync()
