@@ -255,7 +255,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
         if (st.depth == 0 || st.lastSpecular) {
           st.L = st.L + st.beta * Le;
         } else {
-          float const a = st.lastPdf, b = pl / float(nAll);
+          float const a = st.lastPdf, b = pl * (ENV ? 0.5f : 1.f) / float(nAll);
           st.L = st.L + st.beta * Le * ((a * a) / (a * a + b * b));
         }
       }
@@ -292,7 +292,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
   bool areaNee = false;
   if constexpr (AREA) {
     uint32_t const li = pick_index(uLight, nAll);
-    areaNee = li >= sc.lightCount;
+    areaNee = !envNee && li >= sc.lightCount;
     if (areaNee) {
       KArgs const ka = kargs(k);
       uint32_t const ai = li - sc.lightCount;
@@ -302,7 +302,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
         f3 const f = eval_bsdf(b, wo, as.wi, hit.normal, hit.normal, bsdfPdf) * b.weight;
         if (!is_zero(f)) {
           f3 const Le = mk3(ka->areaLe[3 * ai], ka->areaLe[3 * ai + 1], ka->areaLe[3 * ai + 2]);
-          float const a = as.pdf / float(nAll), bb = bsdfPdf;
+          float const a = as.pdf * (ENV ? 0.5f : 1.f) / float(nAll), bb = bsdfPdf;
           put_C(st.beta * (Le * f * (((a * a) / (a * a + bb * bb)) / a)));
           set_shadow_ray(st, offset_ray_origin(hit.pos, hit.error, hit.normal, as.wi), as.wi);
           st.smax = as.dist * 0.999f;
@@ -977,6 +977,9 @@ __global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats_env(RenderParam
 // emissive triangles compiled in (dmt_upload_area_lights selects them)
 __global__ void __launch_bounds__(256, 4) k_megakernel_area(RenderParams P) { megakernel_body<false, false, false, true>(); }
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_area(RenderParams P) { megakernel_body_bvh<false, false, true>(); }
+// both optional light kinds at once
+__global__ void __launch_bounds__(256, 4) k_megakernel_env_area(RenderParams P) { megakernel_body<false, false, true, true>(); }
+__global__ void __launch_bounds__(256, 3) k_megakernel_bvh_env_area(RenderParams P) { megakernel_body_bvh<false, true, true>(); }
 
 // ---------------------------------------------------------------------------------------------
 // device unit-test kernels
@@ -995,7 +998,12 @@ __global__ void k_test_trace(RenderParams P, bool useBvh, int n, int32_t const* 
   for (;;) {
     if (!__any(st.active || st.hasShadow)) break;
     bool const useEnv = kargs(k)->env.w > 0;
-    if (kargs(k)->areaCount > 0) {
+    if (kargs(k)->areaCount > 0 && useEnv) {
+      if (useBvh)
+        lane_step<true, false, true, true>(k, gtid, st, store);
+      else
+        lane_step<false, false, true, true>(k, gtid, st, store);
+    } else if (kargs(k)->areaCount > 0) {
       if (useBvh)
         lane_step<true, false, false, true>(k, gtid, st, store);
       else
@@ -1812,7 +1820,6 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   uint32_t blocks = uint32_t(ctx->cuCount) * uint32_t(blocksPerCuOf(ctx));
   bool const useEnv = ctx->env.w > 0;
   bool const useArea = ctx->areaCount > 0;
-  if (useArea && useEnv) return fail(ctx, DMT_ERR_STATE, "dmt_render: emissive triangles and an env map cannot be combined yet");
   P.env = ctx->env;
   P.areaOf = ctx->d_areaOf, P.areaTri = ctx->d_areaTri, P.areaLe = ctx->d_areaLe, P.areaCount = ctx->areaCount;
   uint32_t const blocksNeeded = (wavesWanted + 3) / 4;
@@ -1860,12 +1867,16 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
       HIP_TRY(ctx, e);
       return DMT_OK;
     }
-    if (useArea)
+    if (useArea && useEnv)
+      hipLaunchKernelGGL(k_megakernel_bvh_env_area, dim3(blocks), dim3(256), 0, ctx->stream, P);
+    else if (useArea)
       hipLaunchKernelGGL(k_megakernel_bvh_area, dim3(blocks), dim3(256), 0, ctx->stream, P);
     else if (useEnv)
       hipLaunchKernelGGL(k_megakernel_bvh_env, dim3(blocks), dim3(256), 0, ctx->stream, P);
     else
       hipLaunchKernelGGL(k_megakernel_bvh, dim3(blocks), dim3(256), 0, ctx->stream, P);
+  } else if (useArea && useEnv) {
+    hipLaunchKernelGGL(k_megakernel_env_area, dim3(blocks), dim3(256), 0, ctx->stream, P);
   } else if (useArea) {
     hipLaunchKernelGGL(k_megakernel_area, dim3(blocks), dim3(256), 0, ctx->stream, P);
   } else if (useEnv) {

@@ -97,7 +97,7 @@ int dmt_set_partition(dmt_ctx* ctx, int rank, int world);
  * reference has no implementation; semantics are pbrt-v4's: one-sided emission on the side of
  * normalize(cross(p1 - p0, p2 - p0)), uniform point sampling, uniform choice among [uploaded lights..., emissive
  * triangles...], power-heuristic MIS.  triangle_index refers to the triangles of the last dmt_upload_triangles (which
- * clears this list); count == 0 removes the lights.  Cannot be combined with an env map yet. */
+ * clears this list); count == 0 removes the lights.  With an env map set, the map still takes half of the NEE samples. */
 int dmt_upload_area_lights(dmt_ctx* ctx, const uint32_t* triangle_index, const float* radiance_rgb, uint32_t count);
 /* A18 -- environment-map light of the reference's CPU renderer (src/core/private/core-light.cpp:84-117,394-491;
  * PiecewiseConstant2D src/core/private/core-math.cu:385-675; MIS rules src/core/private/core-render.cpp:154-163,

@@ -1692,7 +1692,7 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
         if (depth == 0 || specularBounce) {
           L += beta * Le;
         } else {
-          float const a = lastBsdfPdf, b = pl / float(sc.lightCount + sc.areaCount);
+          float const a = lastBsdfPdf, b = pl * (sc.env ? 0.5f : 1.f) / float(sc.lightCount + sc.areaCount);
           L += beta * Le * ((a * a) / (a * a + b * b));
         }
       }
@@ -1711,7 +1711,8 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
     }
     bool areaNee = false;
     uint32_t areaIdx = 0;
-    if (sc.areaCount > 0) {  // uniform choice among point/spot lights and emissive triangles
+    float const listPmfScale = sc.env ? 0.5f : 1.f;  // the env map takes half of the NEE samples when present
+    if (sc.areaCount > 0 && !envNee) {  // uniform choice among point/spot lights and emissive triangles
       uint32_t const li = pickIndex(uLight, sc.lightCount + sc.areaCount);
       areaNee = li >= sc.lightCount;
       areaIdx = areaNee ? li - sc.lightCount : 0u;
@@ -1737,7 +1738,7 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
           V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, hit.normal, hit.normal, &bsdfPdf) * bsdfWeight(bsdf);
           if (!isZero(f)) {
             V3 const Le = v3(sc.areaLe[3 * areaIdx], sc.areaLe[3 * areaIdx + 1], sc.areaLe[3 * areaIdx + 2]);
-            float const a = as.pdf / float(sc.lightCount + sc.areaCount), b = bsdfPdf;
+            float const a = as.pdf * listPmfScale / float(sc.lightCount + sc.areaCount), b = bsdfPdf;
             L += beta * (Le * f * (((a * a) / (a * a + b * b)) / a));
           }
         }

@@ -788,16 +788,29 @@ def test_pbrt_cornell_box_vs_oracle_and_pbrt_image(renderer, pkg, O):
     assert float(np.corrcoef(g1, g2)[0, 1]) > 0.9
 
 
-def test_env_map_and_area_lights_are_mutually_exclusive_for_now(renderer, pkg, O):
-    sc = O.cornell_box(32, 32)
-    sc.set_area_lights([0], [[1, 1, 1]])
-    renderer.upload_scene(sc)
-    renderer.upload_envmap(np.ones((8, 16, 3), np.float32))
+@pytest.mark.parametrize("accel", [0, 1])
+def test_env_map_and_area_lights_together(renderer, pkg, O, accel):
+    """Both optional light kinds at once: the env map takes half of the NEE samples, the uploaded lights and the
+    emissive triangles share the other half (k_megakernel_env_area / k_megakernel_bvh_env_area)."""
+    scene = pkg.host_scene.random_triangle_scene(200, width=40, height=40)
+    osc = O.Scene(scene.xs, scene.ys, scene.zs, scene.mat_id, scene.bsdfs, scene.lights, scene.inf_lights, scene.camera)
+    osc.set_envmap(_envmap(16, seed=5))
+    osc.set_area_lights(np.arange(0, 200, 7), np.tile([[8.0, 6.0, 4.0]], (29, 1)))
+    renderer.upload_scene(osc)
+    renderer.set_limits(6)
+    renderer.set_accel(accel)
+    renderer.set_partition(0, 1)
     try:
-        with pytest.raises(pkg.DmtError, match="cannot be combined"):
-            renderer.render(1)
+        renderer.film_clear()
+        renderer.render(32)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
     finally:
+        renderer.set_accel(0)
         renderer.clear_envmap()
         renderer.upload_area_lights([], np.zeros((0, 3), np.float32))
-    renderer.render(1)
-    renderer.sync()
+    om, om2 = O.render(osc, 32, max_depth=6, threads=8)[:2]
+    assert np.array_equal(m2[..., 3], om2[..., 3])
+    scale = float(om[..., :3].mean())
+    assert scale > 0.2
+    assert float(np.sqrt(np.mean((mean[..., :3] - om[..., :3]) ** 2))) < 2e-3 * scale
