@@ -854,6 +854,10 @@ DMT_DEV void megakernel_body() {
   flush_stats<STATS>(Pk, ls);
 }
 
+#ifndef DMT_BVH_NODE_WEIGHT
+#define DMT_BVH_NODE_WEIGHT 1  // a node step is chosen when nNode * NODE_WEIGHT >= nLeaf * LEAF_WEIGHT: a leaf step (one
+#define DMT_BVH_LEAF_WEIGHT 2  // pair test) costs about half a node step, so it pays from half as many lanes (measured best)
+#endif
 #ifndef DMT_BVH_SHADE_THRESHOLD
 #define DMT_BVH_SHADE_THRESHOLD 32
 #endif
@@ -921,8 +925,8 @@ DMT_DEV void megakernel_body_bvh() {
         }
       }
       // C. traversal.  Lanes sit on an inner node, on a leaf, or have finished their ray.  Each iteration runs ONE
-      //    kind of step -- node or leaf, whichever more lanes are waiting for -- so a step always serves at least
-      //    half of the traversing lanes (a plain while-while loop kept running node steps for the last few lanes
+      //    kind of step -- node or leaf, whichever serves more lanes per instruction (a leaf step costs about half a
+      //    node step) -- so a step always serves a good share of the traversing lanes (a plain while-while loop kept running node steps for the last few lanes
       //    that were still descending: 11 % lane utilisation in node steps).  The loop ends when enough lanes
       //    wait for shading.
       BvhView const bvh = load_bvh(Pk);
@@ -942,7 +946,7 @@ DMT_DEV void megakernel_body_bvh() {
         int const nNode = __popcll(__ballot(onNode)), nLeaf = __popcll(__ballot(onLeaf));
         if (nNode + nLeaf == 0) break;
         if (__popcll(__ballot(tv.phase == TR_DONE)) >= DMT_BVH_SHADE_THRESHOLD) break;
-        if (nNode >= nLeaf) {
+        if (nNode * DMT_BVH_NODE_WEIGHT >= nLeaf * DMT_BVH_LEAF_WEIGHT) {
           if constexpr (STATS) ++ls.itNode;
           if (onNode) trav_node<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
         } else {
