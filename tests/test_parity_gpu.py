@@ -780,7 +780,7 @@ def test_pbrt_cornell_box_vs_oracle_and_pbrt_image(renderer, pkg, O):
     lin = np.clip(mean[..., :3], 0, 1)
     srgb = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(lin, 1 / 2.4) - 0.055)
     img = np.clip(srgb * 255 + 0.5, 0, 255)
-    ref = np.asarray(Image.open(GOLDEN / "pbrt" / "pbrt_output_reference.png"))[..., :3].astype(np.float64)
+    ref = np.asarray(Image.open(GOLDEN / "pbrt" / "pbrt_render_256.png"))[..., :3].astype(np.float64)
     mad = float(np.abs(img - ref).mean())
     mad_mirrored = float(np.abs(img[:, ::-1] - ref).mean())
     assert mad < 16.0 and mad_mirrored > 2.5 * mad, (mad, mad_mirrored)     # same picture, same orientation

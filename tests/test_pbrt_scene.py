@@ -52,12 +52,12 @@ def test_if_the_reference_scene_is_here_it_loads_identically(pkg):
 
 @pytest.mark.parametrize("edit, needle", [
     (lambda t: t.replace('Camera "perspective"', 'Camera "orthographic"'), 'only "perspective"'),
-    (lambda t: t.replace('["diffuse"] "rgb reflectance" [0.63', '["conductor"] "rgb reflectance" [0.63'), 'only "diffuse" materials'),
-    (lambda t: t.replace('  NamedMaterial "green"', '  NamedMaterial "blue"'), "is not defined"),
+    (lambda t: t.replace('[0.63 0.06 0.06] "string type" "diffuse"', '[0.63 0.06 0.06] "string type" "conductor"'), 'only "diffuse" materials'),
+    (lambda t: t.replace('  NamedMaterial "matte_green"', '  NamedMaterial "matte_blue"'), "is not defined"),
     (lambda t: t.replace("WorldBegin", "WorldBegin\nLightSource \"point\""), "'LightSource' is not supported"),
-    (lambda t: t.replace('Shape "trianglemesh" "point3 P" [-1 0 -1   1 0 -1   1 0 1   -1 0 1]', 'Shape "sphere" "point3 P" [-1 0 -1   1 0 -1   1 0 1   -1 0 1]'), 'only "trianglemesh"'),
-    (lambda t: t.replace("0 0 1\nCamera", "0 1 0\nCamera"), "up = +z"),
-    (lambda t: t.replace('"integer indices" [0 1 2  0 2 3]', '"integer indices" [0 1 2  0 2 9]', 1), "index out of range"),
+    (lambda t: t.replace('NamedMaterial "matte_red"\n  Shape "trianglemesh"', 'NamedMaterial "matte_red"\n  Shape "sphere"'), 'only "trianglemesh"'),
+    (lambda t: t.replace("  0 0 1\nCamera", "  0 1 0\nCamera"), "up = +z"),
+    (lambda t: t.replace("      0 2 3\n", "      0 2 9\n", 1), "index out of range"),
     (lambda t: t.replace("AttributeEnd", "", 1) + "\nAttributeEnd\nAttributeEnd\n", "AttributeEnd without AttributeBegin"),
     (lambda t: t.replace('"rgb L" [20 20 20]', '"rgb L" [20 20]'), '"rgb L" with three values'),
 ])

@@ -16,7 +16,7 @@ with pkg.Renderer(0) as r:
 lin = np.clip(mean[..., :3], 0, 1)
 srgb = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(lin, 1 / 2.4) - 0.055)
 img = np.clip(srgb * 255 + 0.5, 0, 255).astype(np.uint8)
-ref = np.asarray(Image.open(ROOT / "tests/golden/pbrt/pbrt_output_reference.png"))[..., :3]
+ref = np.asarray(Image.open(ROOT / "tests/golden/pbrt/pbrt_render_256.png"))[..., :3]
 for name, cand in (("as is", img), ("mirrored", img[:, ::-1])):
     d = cand.astype(np.float64) - ref
     print(name, "mean abs diff /255:", np.abs(d).mean(), "mean signed:", d.mean(axis=(0, 1)), "p95:", np.percentile(np.abs(d), 95))
