@@ -6,6 +6,8 @@
 //   Translate / Scale / Rotate (CTM = CTM * M)                            Identity, Transform / ConcatTransform (16 values)
 //   MakeNamedMaterial name "string type" "diffuse" "rgb reflectance"      NamedMaterial name      Material "diffuse" ...
 //   AreaLightSource "diffuse" "rgb L" [, "float scale"]                   Shape "trianglemesh" "point3 P" "integer indices"
+//   LightSource "point" (I, from) | "spot" (I, from, to, coneangle, conedeltaangle) | "distant" (L, from, to) |
+//               "infinite" (constant L): packed into the reference's own Light records (CC/private/light.cu:271-307)
 //   Option / ColorSpace / Integrator / PixelFilter / Accelerator: accepted and ignored ("integer maxdepth" is read)
 // Everything else is an error that names the directive.
 //
@@ -221,6 +223,12 @@ bool loadPbrtScene(std::string const& path, PbrtScene& out, std::string* error) 
       float L[3];
     };
     std::vector<PendingTri> tris;
+    struct PendingLight {
+      int kind = 0;  // 0 point, 1 spot, 2 distant, 3 infinite (constant)
+      Vec3 color, pos, to;
+      float cos0 = 0.f, cosE = 0.f;
+    };
+    std::vector<PendingLight> lights;
 
     while (tok.kind != Token::End) {
       if (tok.kind != Token::Word) fail("expected a directive, got '" + tok.text + "'");
@@ -307,6 +315,46 @@ bool loadPbrtScene(std::string const& path, PbrtScene& out, std::string* error) 
           if (!two->nums.empty() && two->nums[0] != 0) fail("AreaLightSource: \"bool twosided\" true is not supported");
         gs.emissive = true;
         for (int i = 0; i < 3; ++i) gs.L[i] = float(L->nums[size_t(i)] * sc);
+      } else if (d == "LightSource") {
+        std::string const type = stringArg("LightSource");
+        Params const ps = params();
+        auto rgb = [&](char const* name, Vec3 dflt) {
+          Param const* p = find(ps, "rgb", name);
+          if (!p) return dflt;
+          if (p->nums.size() != 3) fail(std::string("LightSource: \"rgb ") + name + "\" needs three values");
+          return Vec3{float(p->nums[0]), float(p->nums[1]), float(p->nums[2])};
+        };
+        auto point = [&](char const* name, Vec3 dflt) {
+          Param const* p = find(ps, "point3", name);
+          if (!p) p = find(ps, "point", name);
+          if (!p) return dflt;
+          if (p->nums.size() != 3) fail(std::string("LightSource: \"point3 ") + name + "\" needs three values");
+          return Vec3{float(p->nums[0]), float(p->nums[1]), float(p->nums[2])};
+        };
+        double sc = 1;
+        if (Param const* sp = find(ps, "float", "scale")) sc = sp->nums.empty() ? 1 : sp->nums[0];
+        auto scaled = [&](Vec3 v) { return Vec3{float(v.x * sc), float(v.y * sc), float(v.z * sc)}; };
+        Vec3 const from = point("from", Vec3{0, 0, 0}), to = point("to", Vec3{0, 0, 1});
+        Vec3 const wFrom = apply(gs.ctm, from.x, from.y, from.z), wTo = apply(gs.ctm, to.x, to.y, to.z);
+        PendingLight pl;
+        if (type == "point") {
+          pl.kind = 0, pl.color = scaled(rgb("I", Vec3{1, 1, 1})), pl.pos = wFrom;
+        } else if (type == "spot") {
+          pl.kind = 1, pl.color = scaled(rgb("I", Vec3{1, 1, 1})), pl.pos = wFrom, pl.to = wTo;
+          double cone = 30, delta = 5;
+          if (Param const* c = find(ps, "float", "coneangle")) cone = c->nums.empty() ? 30 : c->nums[0];
+          if (Param const* c = find(ps, "float", "conedeltaangle")) delta = c->nums.empty() ? 5 : c->nums[0];
+          double const kRad = 3.14159265358979323846 / 180.0;
+          pl.cos0 = float(std::cos((cone - delta) * kRad)), pl.cosE = float(std::cos(cone * kRad));  // falloff start, total width
+        } else if (type == "distant") {
+          pl.kind = 2, pl.color = scaled(rgb("L", Vec3{1, 1, 1})), pl.pos = wFrom, pl.to = wTo;
+        } else if (type == "infinite") {
+          if (find(ps, "string", "filename")) fail("LightSource \"infinite\": image maps are not supported (use the JSON front-end's envlight)");
+          pl.kind = 3, pl.color = scaled(rgb("L", Vec3{1, 1, 1}));
+        } else {
+          fail("LightSource \"" + type + "\" is not supported");
+        }
+        lights.push_back(pl);
       } else if (d == "Shape") {
         if (!world) fail("Shape before WorldBegin");
         std::string const type = stringArg("Shape");
@@ -376,6 +424,19 @@ bool loadPbrtScene(std::string const& path, PbrtScene& out, std::string* error) 
         out.scene.areaTri.push_back(uint32_t(out.scene.matId.size() - 1));
         out.scene.areaLe.insert(out.scene.areaLe.end(), {t.L[0], t.L[1], t.L[2]});
       }
+    }
+    for (PendingLight const& l : lights) {  // mirrored like the geometry
+      Vec3 const pos = mirror(l.pos), to = mirror(l.to);
+      Vec3 dirv{to.x - pos.x, to.y - pos.y, to.z - pos.z};
+      float const len = std::sqrt(dirv.x * dirv.x + dirv.y * dirv.y + dirv.z * dirv.z);
+      if (l.kind == 1 || l.kind == 2) {
+        if (!(len > 0.f)) fail("LightSource: \"from\" and \"to\" coincide");
+        dirv = Vec3{dirv.x / len, dirv.y / len, dirv.z / len};
+      }
+      if (l.kind == 0) out.scene.lights.push_back(makePointLight(l.color, pos, 1e-3f));
+      else if (l.kind == 1) out.scene.lights.push_back(makeSpotLight(l.color, pos, dirv, l.cos0, l.cosE, 1e-3f));
+      else if (l.kind == 2) out.scene.lights.push_back(makeDirectionalLight(l.color, dirv, 0.f));
+      else out.scene.infiniteLights.push_back(makeEnvironmentalLight(l.color));
     }
     for (Vec3 const& r : materials) out.scene.bsdfs.push_back(makeOrenNayar(r, 0.f));
     if (out.scene.bsdfs.empty()) out.scene.bsdfs.push_back(makeOrenNayar(Vec3{0.5f, 0.5f, 0.5f}, 0.f));

@@ -54,7 +54,9 @@ def test_if_the_reference_scene_is_here_it_loads_identically(pkg):
     (lambda t: t.replace('Camera "perspective"', 'Camera "orthographic"'), 'only "perspective"'),
     (lambda t: t.replace('[0.63 0.06 0.06] "string type" "diffuse"', '[0.63 0.06 0.06] "string type" "conductor"'), 'only "diffuse" materials'),
     (lambda t: t.replace('  NamedMaterial "matte_green"', '  NamedMaterial "matte_blue"'), "is not defined"),
-    (lambda t: t.replace("WorldBegin", "WorldBegin\nLightSource \"point\""), "'LightSource' is not supported"),
+    (lambda t: t.replace("WorldBegin", "WorldBegin\nLightSource \"goniometric\""), 'LightSource "goniometric" is not supported'),
+    (lambda t: t.replace("WorldBegin", "WorldBegin\nLightSource \"infinite\" \"string filename\" \"sky.exr\""), "image maps are not supported"),
+    (lambda t: t.replace("WorldBegin", "WorldBegin\nMakeNamedMedium \"fog\""), "'MakeNamedMedium' is not supported"),
     (lambda t: t.replace('NamedMaterial "matte_red"\n  Shape "trianglemesh"', 'NamedMaterial "matte_red"\n  Shape "sphere"'), 'only "trianglemesh"'),
     (lambda t: t.replace("  0 0 1\nCamera", "  0 1 0\nCamera"), "up = +z"),
     (lambda t: t.replace("      0 2 3\n", "      0 2 9\n", 1), "index out of range"),
@@ -67,3 +69,30 @@ def test_rejections(pkg, tmp_path, edit, needle):
     with pytest.raises(ValueError) as e:
         pkg.host_scene.load_pbrt(p)
     assert needle in str(e.value), str(e.value)
+
+
+def test_light_sources_map_to_the_reference_light_records(pkg, O, tmp_path):
+    """LightSource point / spot / distant / infinite -> the reference's packed Light records (CC/private/light.cu:271-307),
+    positions and directions transformed by the CTM and mirrored with the geometry."""
+    text = SCENE.read_text().replace("WorldBegin", """WorldBegin
+AttributeBegin
+  Translate 0.25 1 0.5
+  LightSource "point" "rgb I" [3 2 1] "point3 from" [0.1 0 0]
+  LightSource "spot" "rgb I" [5 5 4] "point3 from" [0 0 0] "point3 to" [0 1 -1] "float coneangle" 40 "float conedeltaangle" 10 "float scale" 2
+AttributeEnd
+LightSource "distant" "rgb L" [1 1 2] "point3 from" [0 0 1] "point3 to" [1 0 0]
+LightSource "infinite" "rgb L" [0.2 0.3 0.4]
+""")
+    p = tmp_path / "lights.pbrt"
+    p.write_text(text)
+    s = pkg.host_scene.load_pbrt(p)
+    # the camera's right axis is +x here, so mirroring negates x
+    want = [O.make_point_light([3, 2, 1], [-0.35, 1, 0.5], 1e-3),
+            O.make_spot_light([10, 10, 8], [-0.25, 1, 0.5], [0, 2 ** -0.5, -2 ** -0.5], float(np.float32(np.cos(np.radians(30.0)))),
+                              float(np.float32(np.cos(np.radians(40.0)))), 1e-3),
+            O.make_directional_light([1, 1, 2], [-2 ** -0.5, 0, -2 ** -0.5], 0.0)]
+    assert s.lights.shape[0] == 3
+    for got, w in zip(s.lights, want):
+        assert np.array_equal(got, w), (got, w)
+    assert s.inf_lights.shape[0] == 1 and np.array_equal(s.inf_lights[0], O.make_env_light([0.2, 0.3, 0.4]))
+    assert len(s.area_tri) == 2                       # the scene's own emitter is still there
