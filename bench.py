@@ -127,13 +127,12 @@ def main():
     if use_bvh:
         r.set_accel(1)
     r.set_partition(rank, world)
-    mean = torch.zeros((height, width, 4), dtype=torch.float32, device=dev)
-    m2 = torch.zeros((height, width, 4), dtype=torch.float32, device=dev)
+    film = torch.zeros((2, height, width, 4), dtype=torch.float32, device=dev)  # one allocation: one reduce per step
+    mean, m2 = film[0], film[1]
     r.film_bind(mean.data_ptr(), m2.data_ptr())
 
     def step():
-        mean.zero_()
-        m2.zero_()
+        film.zero_()
         for s0 in range(0, spp, kspp):
             r.render(min(kspp, spp - s0), sample_offset=s0)
         pkg.multigpu.combine_films(mean, m2, dst=0)  # disjoint tiles + zero frames: SUM-reduce == exact gather

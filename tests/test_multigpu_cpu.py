@@ -23,12 +23,14 @@ def _worker(rank, world, port, out_path):
     pkg = graft.load_package()
     O = graft.load_oracle()
     scene = O.cornell_box(W, H)
-    mean = np.zeros((H, W, 4), np.float32)
-    m2 = np.zeros((H, W, 4), np.float32)
+    film = np.zeros((2, H, W, 4), np.float32)     # both planes in one allocation, as bench.py holds them:
+    mean, m2 = film[0], film[1]                   # combine_films then needs one collective instead of two
     for tx, ty in pkg.multigpu.owned_tiles(W, H, rank, world):
         O.render(scene, SPP, region=(tx * 8, ty * 8, tx * 8 + 8, ty * 8 + 8), film=(mean, m2), threads=1)
-    tm, tv = torch.from_numpy(mean), torch.from_numpy(m2)
+    tf = torch.from_numpy(film)
+    tm, tv = tf[0], tf[1]
     pkg.multigpu.combine_films(tm, tv, dst=0)
+
     if rank == 0:
         np.savez(out_path, mean=tm.numpy(), m2=tv.numpy())
     dist.barrier()
