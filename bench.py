@@ -135,7 +135,7 @@ def main():
         film.zero_()
         for s0 in range(0, spp, kspp):
             r.render(min(kspp, spp - s0), sample_offset=s0)
-        pkg.multigpu.combine_films(mean, m2, dst=0)  # disjoint tiles + zero frames: SUM-reduce == exact gather
+        pkg.multigpu.combine_films(mean, m2, dst=0, film=film)  # disjoint tiles + zero frames: SUM-reduce == exact gather
 
     def barrier():
         if world > 1:

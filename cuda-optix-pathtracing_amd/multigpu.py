@@ -36,15 +36,13 @@ def owned_pixel_mask(width, height, rank, world, region=None):
     return mask
 
 
-def combine_films(mean, m2, dst=0):
-    """SUM-reduce the two film planes (torch tensors, full frames, zero outside the owned tiles) to `dst`."""
+def combine_films(mean, m2, dst=0, film=None):
+    """SUM-reduce the two film planes (torch tensors, full frames, zero outside the owned tiles) to `dst`.
+    `film`: optionally the single tensor both planes are views of ([2, h, w, 4]); then one collective does it."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        # one collective when the two planes are halves of one allocation (bench.py lays them out that way)
-        if (mean.is_contiguous() and m2.is_contiguous() and mean.untyped_storage().data_ptr() == m2.untyped_storage().data_ptr()
-                and m2.storage_offset() == mean.storage_offset() + mean.numel()):
-            both = mean.new_empty(0).set_(mean.untyped_storage(), mean.storage_offset(), (2 * mean.numel(),))
-            dist.reduce(both, dst=dst, op=dist.ReduceOp.SUM)
+        if film is not None:
+            dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
         else:
             dist.reduce(mean, dst=dst, op=dist.ReduceOp.SUM)
             dist.reduce(m2, dst=dst, op=dist.ReduceOp.SUM)

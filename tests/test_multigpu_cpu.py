@@ -29,7 +29,7 @@ def _worker(rank, world, port, out_path):
         O.render(scene, SPP, region=(tx * 8, ty * 8, tx * 8 + 8, ty * 8 + 8), film=(mean, m2), threads=1)
     tf = torch.from_numpy(film)
     tm, tv = tf[0], tf[1]
-    pkg.multigpu.combine_films(tm, tv, dst=0)
+    pkg.multigpu.combine_films(tm, tv, dst=0, film=tf)
 
     if rank == 0:
         np.savez(out_path, mean=tm.numpy(), m2=tv.numpy())
