@@ -15,8 +15,24 @@ The frame is partitioned by interleaved 8x8 tiles (tile j -> rank j mod N), tota
 PyTorch is plumbing here (device buffers for the film, streams, torch.distributed); every sample is
 traced by csrc/libdmt_hip.so through the C ABI.  The CPU oracle is used ONLY in the cpu_baseline
 leg (rank 0, N == 1), where it is the thing timed on the host cores and, as a by-product, supplies
-the per-sample work counters for the algorithmic-bytes model and a band to check the GPU film
-against.
+the per-sample work counters for the flop / byte models and a band to check the GPU film against.
+
+Roofline record (`roofline`): the bound that limits each workload's kernel, as a fraction <= 1.
+  * Cornell workloads (26 triangles, k_megakernel): the scene lives in SGPRs / the scalar cache and the only compulsory
+    HBM traffic is the film, so the kernel is VALU bound (the reference's authors found the same on their GPU:
+    98 FLOP/B, docs/dmt-mk_roofline_point.txt).  bound = "valu": achieved = useful fp32 FLOP/s from the FLOP model
+    below over the live HIP-event kernel time, peak = 157.3 TFLOP/s (MI355X_MICROARCH.md).  Next to it: `issue_view`
+    (VALU pipe busy from the committed PMC pass) and `hbm_view` (PMC FETCH/WRITE bytes over the live time).
+  * BVH workloads (k_megakernel_bvh*): bound = "hbm": achieved = HBM bytes per launch from the PMC passes
+    (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE, collected by tools/pmc_workload.sh, committed in
+    profiles/pmc_summary.json) over the live kernel time, peak 8 TB/s spec (6.29 TB/s measured copy in the guide,
+    reported as frac_of_measured_peak).  When no PMC record exists for the workload, achieved / frac are null.
+  * `cache_level_rate` keeps SURVEY 8(d)'s algorithmic-bytes figure (bytes the algorithm asks for per sample x samples /
+    time).  It is served by the scalar cache / L2 / Infinity Cache, NOT by HBM, and may exceed the HBM peak; it is
+    labelled as such and never used as `frac`.
+FLOP model: 60 flop per triangle test + 60 per BVH node visit (4 slab tests) + 620 per bounce (shading,
+sampler: what remains of the authors' nvprof count of 17.9 kFLOP per sample on the same scene at 250.7 tests and
+4.65 bounces per sample, docs/dmt-mk_roofline_point.txt:2-6).
 """
 import argparse
 import json
@@ -29,27 +45,40 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_MEASURED_GBS = 6290.0      # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy); this box: copy 4.7, triad 5.9, fill 6.8
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+SIMDS = 1024                   # 256 CUs x 4
+FLOP_PER_TRI_TEST = 60.0
+FLOP_PER_NODE_VISIT = 60.0
+FLOP_PER_BOUNCE = 620.0
 
 WORKLOADS = {
     # name: (width, height, spp, max_depth, scene)
     "cornell_1024x1024_1024spp_8bounces": (1024, 1024, 1024, 8, "cornell"),
     "cornell_256x256_2048spp_32bounces": (256, 256, 2048, 32, "cornell"),   # the reference's own published run
     "cornell_512x512_64spp_4bounces": (512, 512, 64, 4, "cornell"),         # BASELINE configs[0]
-    # BASELINE configs[3]: 1 M random triangles (SURVEY 8d generator), the memory-bound point; BVH traversal
+    # BASELINE configs[3]: 1 M random triangles (SURVEY 8d generator); BVH traversal.  102 MB of nodes + leaves:
+    # resident in the 256 MiB Infinity Cache
     "random1M_1024x1024_512spp_8bounces": (1024, 1024, 512, 8, "random1M"),
-    # BASELINE configs[2] with synthetic assets (the reference's sphere.fbx / veranda map are not on the GPU box):
-    # tessellated sphere + ground plane under an importance-sampled HDR sky (A18 env-map kernels, NEE + MIS), BVH
+    # the same generator at 16 M triangles: nodes + leaves (1.6 GB) exceed the Infinity Cache -> the HBM-roofline point
+    "random16M_1024x1024_64spp_8bounces": (1024, 1024, 64, 8, "random16M"),
+    # BASELINE configs[2] on its named assets: the reference's scenes/sphere.fbx under scenes/veranda_polyhaven_1k.png,
+    # scene description scenes/fbx_example.json (committed as data under tests/golden/c3/), film 256x256 as the JSON says
+    "sphere_fbx_veranda_256x256_2048spp_12bounces": (256, 256, 2048, 12, "c3_assets"),
+    # BASELINE configs[2] with synthetic assets at 1024^2 (tessellated sphere + ground under a synthetic HDR sky)
     "sphere_envmap_1024x1024_2048spp_8bounces": (1024, 1024, 2048, 8, "sphere_env"),
     # BASELINE configs[4]: the frame the reference quotes for 8 GPUs; runs on any N (strong scaling)
     "cornell_4096x4096_4096spp_8bounces": (4096, 4096, 4096, 8, "cornell"),
 }
-BVH_NODE_BYTES = 128
+RANDOM_SCENE_TRIANGLES = {"random1M": 1_000_000, "random16M": 16_000_000}
+BVH_NODE_BYTES = 128           # csrc/bvh.hpp Bvh4Node
+BVH_LEAF_BYTES_PER_TRI = 64    # csrc/bvh.hpp TriPair: 128 B per pair
 DEFAULT_WORKLOAD = "cornell_1024x1024_1024spp_8bounces"
+C1_WORKLOAD = "cornell_512x512_64spp_4bounces"
 
-# Per-sample work counters of each workload, counted by the CPU restatement on rows spread evenly over
+# Per-sample work counters of the Cornell workloads, counted by the CPU restatement on rows spread evenly over
 # the frame (same procedure as the cpu_baseline leg below, which recounts them live when it runs).
-# Only used for the algorithmic-bytes model when the cpu_baseline leg is skipped (N > 1, --no-cpu-baseline).
+# Used for the flop / byte models when the cpu_baseline leg is skipped (N > 1, --no-cpu-baseline).
 WORKLOAD_STATS = {
     "cornell_1024x1024_1024spp_8bounces": {"samples": 1.0, "closest_rays": 3.6101, "shadow_rays": 3.1595,
                                            "tri_tests": 173.8335, "bounces": 3.1595, "hits": 3.1595},
@@ -57,15 +86,122 @@ WORKLOAD_STATS = {
                                           "tri_tests": 250.6595, "bounces": 4.6513, "hits": 4.6513},
     "cornell_512x512_64spp_4bounces": {"samples": 1.0, "closest_rays": 3.1490, "shadow_rays": 2.6932,
                                        "tri_tests": 150.0929, "bounces": 2.6932, "hits": 2.6932},
+    # same scene, camera and cap as the 1024^2 workload: per-sample counters agree to 3 digits (4 rows x 64 spp counted)
+    "cornell_4096x4096_4096spp_8bounces": {"samples": 1.0, "closest_rays": 3.6101, "shadow_rays": 3.1595,
+                                           "tri_tests": 173.8335, "bounces": 3.1595, "hits": 3.1595},
 }
 
 
-def algorithmic_bytes_per_sample(stats, spp_per_launch):
-    """B_sample = B_film + sum_rays[N_tris * 48] + N_bounces * (32 + 32) + N_hits * 4,
-    counted by the CPU restatement on the same rays (brute force: no BVH nodes)."""
+def algorithmic_bytes_per_sample(stats, spp_per_launch, node_bytes=0.0, tri_bytes=48.0):
+    """B_sample = B_film + sum_rays[N_nodes * S_node + N_tris * 48] + N_bounces * (32 + 32) + N_hits * 4,
+    counted on the same rays (brute force: no BVH nodes; BVH: S_node and the leaf bytes per triangle of csrc/bvh.hpp)."""
     n = float(stats["samples"])
     b_film = 64.0 / spp_per_launch
-    return b_film + (stats["tri_tests"] * 48.0 + stats["bounces"] * 64.0 + stats["hits"] * 4.0) / n
+    return b_film + (stats["tri_tests"] * tri_bytes + stats.get("node_visits", 0.0) * node_bytes +
+                     stats["bounces"] * 64.0 + stats["hits"] * 4.0) / n
+
+
+def flops_per_sample(stats):
+    n = float(stats["samples"])
+    return (stats["tri_tests"] * FLOP_PER_TRI_TEST + stats.get("node_visits", 0.0) * FLOP_PER_NODE_VISIT +
+            stats["bounces"] * FLOP_PER_BOUNCE) / n
+
+
+def kernel_name(scene_kind):
+    if scene_kind == "cornell":
+        return "k_megakernel"
+    return "k_megakernel_bvh_env" if scene_kind in ("sphere_env", "c3_assets") else "k_megakernel_bvh"
+
+
+def load_pmc(workload, kspp):
+    """profiles/pmc_summary.json record of this workload (written by tools/pmc_summarize.py from rocprofv3 --pmc passes)."""
+    pmc = ROOT / "profiles" / "pmc_summary.json"
+    try:
+        j = json.loads(pmc.read_text())["workloads"].get(workload)
+        return j if j and j.get("kspp") == kspp else None
+    except Exception:
+        return None
+
+
+def build_roofline(workload, stats, avg_ms, samples_per_launch, kspp, pmc, info=None):
+    """The `roofline` object of the JSON line (pure function: exercised on CPU by tests/test_bench_contract.py).
+    stats: per-workload work counters or None; pmc: load_pmc() record or None."""
+    scene_kind = WORKLOADS[workload][4]
+    use_bvh = scene_kind != "cornell"
+    secs = avg_ms * 1e-3
+    traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+    hbm_view = None
+    if traffic is not None and secs > 0:
+        gbs = traffic / secs / 1e9
+        hbm_view = {"traffic_bytes_per_launch": traffic, "GB/s": round(gbs, 2),
+                    "frac_of_spec_peak": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_peak": round(gbs / HBM_MEASURED_GBS, 4),
+                    "source": "profiles/pmc_summary.json: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, separate --pmc passes; live kernel time"}
+    valu_view = issue_view = cache_rate = None
+    if stats is not None and secs > 0:
+        tf = flops_per_sample(stats) * samples_per_launch / secs / 1e12
+        valu_view = {"achieved_tflops": round(tf, 3), "peak_tflops": FP32_VALU_PEAK_TFLOPS, "frac": round(tf / FP32_VALU_PEAK_TFLOPS, 4),
+                     "flops_per_sample": round(flops_per_sample(stats), 1),
+                     "flops_model": "60 x triangle tests + 60 x BVH node visits + 620 x bounces (see module docstring)"}
+        b_sample = algorithmic_bytes_per_sample(stats, kspp, BVH_NODE_BYTES if use_bvh else 0.0,
+                                                BVH_LEAF_BYTES_PER_TRI if use_bvh else 48.0)
+        cache_rate = {"algorithmic_bytes_per_sample": round(b_sample, 1),
+                      "GB/s": round(b_sample * samples_per_launch / secs / 1e9, 1),
+                      "note": "SURVEY 8(d) algorithmic bytes over kernel time: served by the scalar cache / L2 / Infinity Cache, "
+                              "not an HBM rate (can exceed the HBM peak); HBM traffic is hbm_view"}
+    if pmc and pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("kernel_ms"):
+        clk = pmc.get("clock_ghz") or 2.4
+        busy = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * pmc["kernel_ms"] * 1e-3 * clk * 1e9)
+        issue_view = {"valu_busy": round(min(busy, 1.0), 4), "raw": round(busy, 4), "clock_ghz": clk,
+                      "formula": "SQ_ACTIVE_INST_VALU x 4 (quad-cycles) / (1024 SIMDs x kernel s x clock); clock = GRBM_GUI_ACTIVE / 8 / kernel s "
+                                 "of the same PMC run (2.4 GHz when absent)",
+                      "lane_utilisation": pmc.get("lane_utilisation"), "wait_any_share": pmc.get("wait_any_share"),
+                      "valu_insts_per_sample": pmc.get("valu_insts_per_sample")}
+    out = {"kernel": kernel_name(scene_kind), "avg_launch_ms": round(avg_ms, 4), "traffic": traffic,
+           "hbm_view": hbm_view, "valu_view": valu_view, "issue_view": issue_view, "cache_level_rate": cache_rate}
+    if not use_bvh:
+        out.update({"bound": "valu", "unit": "TFLOP/s", "peak": FP32_VALU_PEAK_TFLOPS,
+                    "achieved": valu_view["achieved_tflops"] if valu_view else None,
+                    "frac": valu_view["frac"] if valu_view else None,
+                    "note": "26-triangle scene is SGPR / scalar-cache resident, compulsory HBM traffic is the film only: VALU bound "
+                            "(SURVEY 8d).  frac = useful fp32 FLOP/s / 157.3 TF; the VALU pipe itself is ~saturated (issue_view): "
+                            "the gap is lane utilisation, integer/address/compare work and non-FMA instructions"})
+    else:
+        out.update({"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                    "achieved": hbm_view["GB/s"] if hbm_view else None,
+                    "frac": hbm_view["frac_of_spec_peak"] if hbm_view else None,
+                    "note": "BVH traversal: per-lane gathers of nodes and triangle-pair leaves (csrc/bvh.hpp); achieved = HBM bytes moved "
+                            "(PMC) / live kernel time.  Scenes that fit the 256 MiB Infinity Cache are latency / divergence "
+                            "bound far below the HBM roof (issue_view.wait_any_share); random16M exceeds it"})
+    assert out["frac"] is None or out["frac"] <= 1.0, out
+    if stats is not None:
+        out["per_sample"] = {k: round(v / stats["samples"], 3) for k, v in stats.items() if k != "samples"}
+    if info:
+        out.update({"vgprs": info["vgprs"], "lds_bytes_per_block": info["lds_bytes"], "blocks_per_cu": info["blocks_per_cu"],
+                    "cu_count": info["cu_count"]})
+    return out
+
+
+def cpu_model():
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def build_scene(pkg, scene_kind, width, height):
+    hs = pkg.host_scene
+    if scene_kind == "cornell":
+        return hs.cornell_box(width, height)
+    if scene_kind == "sphere_env":
+        return hs.sphere_envmap_scene(width, height)
+    if scene_kind == "c3_assets":
+        s = hs.load_json(ROOT / "tests" / "golden" / "c3" / "c3_sphere_veranda.json")
+        assert (s.width, s.height) == (width, height)
+        return s
+    return hs.random_triangle_scene(RANDOM_SCENE_TRIANGLES[scene_kind], width=width, height=height)
 
 
 def main():
@@ -108,12 +244,7 @@ def main():
     width, height, spp, max_depth, scene_kind = WORKLOADS[args.workload]
     kspp = args.kspp if args.kspp > 0 else spp
     use_bvh = scene_kind != "cornell"
-    if scene_kind == "cornell":
-        scene = pkg.host_scene.cornell_box(width, height)
-    elif scene_kind == "sphere_env":
-        scene = pkg.host_scene.sphere_envmap_scene(width, height)
-    else:
-        scene = pkg.host_scene.random_triangle_scene(1_000_000, width=width, height=height)
+    scene = build_scene(pkg, scene_kind, width, height)
 
     r = pkg.Renderer(dev_index)
     # one explicit (non-null) stream for everything: film zeroing, kernels + their HIP timing events,
@@ -157,9 +288,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches = r.kernel_time(reset=True)
+    r.sync()   # every rank: raises DmtError if a fold gave up waiting (in-launch ordering) -> non-zero exit, no JSON line
 
     total_samples = float(width) * height * spp * args.steps
     value = total_samples / elapsed / 1e6
+    exit_code = 0
 
     if rank == 0:
         film_mean = mean.cpu().numpy()
@@ -168,10 +301,8 @@ def main():
         info = r.kernel_info()
 
         cpu_baseline = None
-        roofline = None
         parity = None
         stats = None
-        bvh_stats = None
         if use_bvh:
             # BVH path: node visits / triangle tests come from the counting build of the same kernel
             # (1 spp over the whole frame; the film is rebuilt by nothing afterwards -- timing is done)
@@ -182,7 +313,7 @@ def main():
                      "node_visits": bvh_stats["node_visits"], "closest_rays": bvh_stats["closest_rays"],
                      "shadow_rays": bvh_stats["shadow_rays"]}
             if not args.no_cpu_baseline and world == 1:
-                # the reference arithmetic is brute force: 1 M triangle tests per ray.  32 samples only.
+                # the reference arithmetic is brute force: every triangle tested per ray.  A handful of samples only.
                 O = graft.load_oracle()
                 oscene = O.Scene(scene.xs, scene.ys, scene.zs, scene.mat_id, scene.bsdfs, scene.lights,
                                  scene.inf_lights, scene.camera)
@@ -190,96 +321,78 @@ def main():
                     oscene.set_envmap(scene.env_rgb, scene.env_quat, scene.env_scale)
                 threads = int(os.environ.get("DMT_CPU_THREADS", min(os.cpu_count() or 1, 16)))
                 y = height // 2
+                # bounded sample: ~2e9 triangle tests
+                npx = int(max(16, min(width, 2e9 / max(1, scene.tri_count) / 8)))
+                ospp = 1 if scene.tri_count > 100_000 else min(spp, 64)
+                x0 = width // 2 - npx // 2
                 tc = time.perf_counter()
-                omean, om2, ost = O.render(oscene, 1, max_depth=max_depth, region=(width // 2 - 16, y, width // 2 + 16, y + 1),
+                omean, om2, ost = O.render(oscene, ospp, max_depth=max_depth, region=(x0, y, x0 + npx, y + 1),
                                            threads=threads, want_stats=True)
                 tcpu = time.perf_counter() - tc
                 cpu_baseline = {
                     "value": round(ost["samples"] / tcpu / 1e6, 8), "unit": "Msamples/s", "cores": threads, "kind": "port",
-                    "sample": f"32 pixels x 1 spp of row {y} ({tcpu:.1f} s); the reference arithmetic is a brute-force loop "
+                    "cpu": cpu_model(),
+                    "sample": f"{npx} pixels x {ospp} spp of row {y} ({tcpu:.1f} s); the reference arithmetic is a brute-force loop "
                               f"over all {scene.tri_count:,} triangles per ray (megakernel.cu:121-133), no BVH",
                 }
-                d = film_mean[y, width // 2 - 16:width // 2 + 16, :3].astype(np.float64)
-                # spp differs (1 vs 0) so this is not a parity figure; parity of the BVH path is tests/test_parity_gpu.py::test_bvh_*
+                if ospp == spp:
+                    d = film_mean[y:y + 1, x0:x0 + npx, :3].astype(np.float64) - omean[y:y + 1, x0:x0 + npx, :3]
+                    parity = {"rmse_vs_cpu_rows": float(np.sqrt((d ** 2).mean(axis=2)).mean()), "tolerance": 1e-3}
         elif not args.no_cpu_baseline and world == 1:
             O = graft.load_oracle()          # cpu_baseline leg: the oracle is the thing timed
-            oscene = O.cornell_box(width, height)
-            # bounded CPU sample: at most ~6e7 path samples (about 20 s on 16 threads)
-            nrows = max(1, min(args.cpu_band_rows, height, int(6e7 // (width * spp)) or 1))
-            rows = sorted({int((i + 0.5) * height / nrows) for i in range(nrows)})
             # the 1-GPU box exposes 256 logical CPUs but the job's CPU share is 16 cores
             threads = int(os.environ.get("DMT_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+            # (1) timed: BASELINE configs[0] / BASELINE.md "CPU-baseline plan": the whole 512 x 512 x 64 spp frame, cap 4
+            cw, ch, cspp, cdepth, _ = WORKLOADS[C1_WORKLOAD]
+            c1scene = O.cornell_box(cw, ch)
+            tc = time.perf_counter()
+            _, _, c1st = O.render(c1scene, cspp, max_depth=cdepth, threads=threads, want_stats=True)
+            tcpu = time.perf_counter() - tc
+            cpu_baseline = {
+                "value": round(c1st["samples"] / tcpu / 1e6, 4), "unit": "Msamples/s", "cores": threads,
+                "kind": "port", "cpu": cpu_model(),
+                "sample": f"BASELINE configs[0] in full: cornellBox {cw}x{ch}, {cspp} spp, bounce cap {cdepth} "
+                          f"({c1st['samples']} samples, {tcpu:.1f} s); CPU restatement of the reference arithmetic "
+                          f"(oracle/dmt_oracle.cpp, g++ -O2 -ffp-contract=off), 32x32-tile std::thread pool",
+            }
+            # (2) untimed: rows of THIS workload's frame -> work counters for the models + a parity band for the GPU film
+            oscene = O.cornell_box(width, height)
+            nrows = max(1, min(args.cpu_band_rows, height, int(2e7 // (width * spp)) or 1))
+            rows = sorted({int((i + 0.5) * height / nrows) for i in range(nrows)})
             stats = {}
             omean = np.zeros((height, width, 4), np.float32)
             om2 = np.zeros((height, width, 4), np.float32)
-            tc = time.perf_counter()
             for y in rows:
                 _, _, st = O.render(oscene, spp, max_depth=max_depth, region=(0, y, width, y + 1), threads=threads,
                                     film=(omean, om2), want_stats=True)
                 for k, v in st.items():
                     stats[k] = stats.get(k, 0) + v
-            tcpu = time.perf_counter() - tc
-            cpu_baseline = {
-                "value": round(stats["samples"] / tcpu / 1e6, 4), "unit": "Msamples/s", "cores": threads,
-                "kind": "port",
-                "sample": f"{len(rows)} rows spread evenly over the {width}x{height} frame, all {spp} spp, bounce cap "
-                          f"{max_depth} ({stats['samples']} samples, {tcpu:.1f} s); CPU restatement of the reference "
-                          f"arithmetic, 32x32-tile std::thread pool",
-            }
             d = film_mean[rows, :, :3].astype(np.float64) - omean[rows, :, :3]
-            parity = {"rmse_vs_cpu_rows": float(np.sqrt((d ** 2).mean(axis=2)).mean()), "tolerance": 1e-3}
+            parity = {"rmse_vs_cpu_rows": float(np.sqrt((d ** 2).mean(axis=2)).mean()), "tolerance": 1e-3,
+                      "rows": len(rows), "samples": int(stats["samples"])}
         if stats is None:
-            stats = WORKLOAD_STATS[args.workload]
-        if launches > 0 and stats["tri_tests"] > 0:
-            avg_ms = kernel_ms / launches
-            my_items = (width // 8) * (height // 8)
-            samples_per_launch = float(width) * height * kspp / world
-            b_sample = algorithmic_bytes_per_sample(stats, kspp)
-            if use_bvh:
-                b_sample += stats["node_visits"] * float(BVH_NODE_BYTES) / stats["samples"]
-            achieved = b_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = ROOT / "profiles" / "pmc_summary.json"
-            if pmc.exists():
-                try:
-                    j = json.loads(pmc.read_text())["workloads"].get(args.workload)
-                    if j and j.get("kspp") == kspp:
-                        traffic = j.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            flops_per_sample = (stats["tri_tests"] * 60.0) / stats["samples"]   # ~60 flop per triangle test
-            roofline = {
-                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": ("k_megakernel_bvh_env" if scene_kind == "sphere_env" else "k_megakernel_bvh") if use_bvh else "k_megakernel", "avg_launch_ms": round(avg_ms, 4), "launches": int(launches),
-                "algorithmic_bytes_per_sample": round(b_sample, 1),
-                "note": ("BVH traversal + env-map NEE/MIS kernels; nodes, triangle pairs and the 10 MiB of env-map tables are "
-                         "cache resident" if scene_kind == "sphere_env" else
-                         "1 M triangles + BVH nodes (110 MB) exceed the 32 MB of L2 but sit in the 256 MiB Infinity Cache: "
-                         "the per-lane incoherent node/triangle gathers are served from there, so achieved algorithmic "
-                         "GB/s can approach or exceed the HBM peak; the kernel is divergence/latency bound" if use_bvh else
-                         "26-triangle scene is cache/SGPR resident: algorithmic bytes are served by the scalar cache, "
-                         "the kernel is VALU/latency bound (SURVEY 8d); see valu_view"),
-                "per_sample": {k: round(v / stats["samples"], 3) for k, v in stats.items() if k != "samples"},
-                "valu_view": {
-                    "achieved_tflops": round(flops_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e12, 3),
-                    "peak_tflops": FP32_VALU_PEAK_TFLOPS,
-                    "flops_model": "60 flop x triangle tests (intersection only; shading and sampler not counted)",
-                },
-                "vgprs": info["vgprs"], "lds_bytes_per_block": info["lds_bytes"], "blocks_per_cu": info["blocks_per_cu"],
-                "cu_count": info["cu_count"],
-            }
+            stats = WORKLOAD_STATS.get(args.workload)
+        roofline = None
+        if launches > 0:
+            roofline = build_roofline(args.workload, stats, kernel_ms / launches, float(width) * height * kspp / world, kspp,
+                                      load_pmc(args.workload, kspp), info)
+            roofline["launches"] = int(launches)
 
+        scene_text = {
+            "cornell": "cornellBox() (26 triangles, spot + constant env)",
+            "random1M": "1,000,000 random triangles, splitmix64 seed 0x5EED1234 (SURVEY 8d), Cornell BSDFs, spot + env",
+            "random16M": "16,000,000 random triangles, same generator: BVH nodes + leaves exceed the 256 MiB Infinity Cache",
+            "c3_assets": f"the reference's scenes/sphere.fbx ({scene.tri_count} triangles, GGX conductor) under "
+                         "scenes/veranda_polyhaven_1k.png as importance-sampled env map (A18), spot light; scenes/fbx_example.json, "
+                         "mesh in metres (tests/test_configs_gpu.py docstring)",
+            "sphere_env": f"UV sphere ({scene.tri_count:,} triangles incl. ground plane, GGX conductor + Oren-Nayar), "
+                          "synthetic 1024x512 HDR sky as importance-sampled env map (A18), one spot light"}[scene_kind]
         out = {
             "metric": "Msamples/s (paths x spp / s)", "value": round(value, 3), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload,
-                       "scene": {"cornell": "cornellBox() (26 triangles, spot + constant env)",
-                                 "random1M": "1,000,000 random triangles, splitmix64 seed 0x5EED1234 (SURVEY 8d), Cornell BSDFs, spot + env",
-                                 "sphere_env": f"UV sphere ({scene.tri_count:,} triangles incl. ground plane, GGX conductor + Oren-Nayar), "
-                                               "synthetic 1024x512 HDR sky as importance-sampled env map (A18), one spot light"}[scene_kind],
+            "config": {"workload": args.workload, "scene": scene_text,
                        "width": width, "height": height, "spp": spp, "max_depth": max_depth, "kspp": kspp,
                        "accel": "bvh4" if use_bvh else "brute_force", "partition": f"interleaved 8x8 tiles over {world} GPU(s)",
                        "combine": "rccl reduce(sum) of mean/M2 frames to rank 0" if world > 1 else "none"},
@@ -287,11 +400,15 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
         print(json.dumps(out), flush=True)
+        if not counts_ok or (parity is not None and not parity["rmse_vs_cpu_rows"] < parity["tolerance"]):
+            print("bench.py: film check FAILED (sample counts / finiteness / parity band)", file=sys.stderr, flush=True)
+            exit_code = 3
     r.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return exit_code
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -254,7 +254,7 @@ class Renderer:
         self._check(self._lib.dmt_render_profile(self._ctx, C.c_uint32(sample_offset), C.c_uint32(spp), int(x0), int(y0),
                                                  int(x1), int(y1), _p(out)), "dmt_render_profile")
         keys = ["samples", "closest_rays", "shadow_rays", "node_visits", "tri_tests", "bounces", "it_node", "it_leaf",
-                "it_shade", "it_outer", "it_prep", "lanes_leaf", "lanes_shade", "lanes_prep", "dead_nodes"]
+                "it_shade", "it_outer", "it_prep", "lanes_leaf", "lanes_shade", "lanes_prep", "dead_nodes", "overflow_pushes"]
         return dict(zip(keys, (int(v) for v in out)))
 
     def sync(self):

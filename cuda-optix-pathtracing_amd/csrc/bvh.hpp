@@ -28,7 +28,10 @@ constexpr uint32_t kBvhLeafFlag = 0x80000000u;
 constexpr uint32_t kBvhEmpty = 0xFFFFFFFFu;
 constexpr int kBvhMaxLeafTris = 2;   // one triangle pair per leaf: measured best (1 M random triangles: 405 vs 391 Msamples/s for 4)
 constexpr int kBvhMaxDepth = 48;   // depth bound (binary levels, hence also 4-wide levels) enforced by the builder
-constexpr int kBvhLdsStack = 16;   // traversal stack entries kept in LDS per lane
+#ifndef DMT_BVH_LDS_STACK
+#define DMT_BVH_LDS_STACK 16  // tests build a variant with 2 so that every non-trivial traversal runs through the global overflow stack
+#endif
+constexpr int kBvhLdsStack = DMT_BVH_LDS_STACK;   // traversal stack entries kept in LDS per lane
 constexpr int kBvhOverflowStack = 3 * kBvhMaxDepth - kBvhLdsStack;  // the rest, per lane, in global memory
 
 // child reference: kBvhEmpty | inner node index | kBvhLeafFlag | (count-1) << 28 | first

@@ -27,11 +27,14 @@ struct BvhStack {
   int sp;
   uint32_t* ovf;  // this lane's overflow column
   uint32_t stride;
+  uint32_t* ovfCount = nullptr;  // stats build only: counts the pushes that went to the global overflow area
   DMT_DEV void push(uint32_t ref) {
-    if (sp < kBvhLdsStack)
+    if (sp < kBvhLdsStack) {
       s_bvh_stack[sp * kLdsThreads + int(threadIdx.x)] = ref;
-    else
+    } else {
       ovf[size_t(sp - kBvhLdsStack) * stride] = ref;
+      if (ovfCount) ++*ovfCount;
+    }
     ++sp;
   }
   DMT_DEV uint32_t pop() {
@@ -98,6 +101,7 @@ DMT_DEV PairHit pair_test(TriPair const& P, f3 o, f3 d) {
 struct TraversalCounters {  // per-lane work counters (stats build of the kernel only)
   uint32_t nodes = 0, tris = 0;
   uint32_t deadNodes = 0;  // visited nodes none of whose children was entered or pushed
+  uint32_t overflowPushes = 0;  // stack pushes that went to the global overflow area (entries >= kBvhLdsStack)
 };
 
 // closest hit: bestTri = ORIGINAL triangle index or -1

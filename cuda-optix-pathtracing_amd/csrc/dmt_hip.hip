@@ -814,6 +814,7 @@ DMT_DEV void flush_stats(KArgs Pk, LaneStats const& ls) {
     atomicAdd(&stats[12], (unsigned long long)ls.lanesShade);
     atomicAdd(&stats[13], (unsigned long long)ls.lanesPrep);
     atomicAdd(&stats[14], (unsigned long long)ls.tc.deadNodes);
+    atomicAdd(&stats[15], (unsigned long long)ls.tc.overflowPushes);
   }
 }
 
@@ -883,6 +884,7 @@ DMT_DEV void megakernel_body_bvh() {
     BvhView const bvh0 = load_bvh(Pk);
     tv.stack.ovf = bvh0.overflow + gtid;
     tv.stack.stride = bvh0.overflowStride;
+    if constexpr (STATS) tv.stack.ovfCount = &ls.tc.overflowPushes;
   }
   if (sched_begin(Pk, lane, W)) {
     for (;;) {
@@ -1471,6 +1473,18 @@ struct Scratch {
 #define SCRATCH_CHECK(ctx, p) \
   if (!(p)) return fail(ctx, DMT_ERR_HIP, "scratch allocation / upload failed")
 
+// After the stream has drained: has any wave of a past launch given up waiting for a tile's previous sample chunk
+// (item_fold)?  Then the film is not the ordered fold the contract promises.  Reads and clears the flag.
+int checkErrorFlag(dmt_ctx* ctx) {
+  uint32_t flag = 0;
+  HIP_TRY(ctx, hipMemcpy(&flag, ctx->d_counter + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (flag) {
+    (void)hipMemset(ctx->d_counter + 1, 0, sizeof(uint32_t));
+    return fail(ctx, DMT_ERR_HIP, "a wave gave up waiting for a tile's previous sample chunk (in-launch ordering): the film is invalid");
+  }
+  return DMT_OK;
+}
+
 int finishTest(dmt_ctx* ctx) {
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1755,6 +1769,7 @@ int dmt_download_film(dmt_ctx* ctx, float* mean4, float* m24) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   size_t const bytes = size_t(ctx->filmW) * size_t(ctx->filmH) * sizeof(float4);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int const rc = checkErrorFlag(ctx)) return rc;
   if (mean4) HIP_TRY(ctx, hipMemcpy(mean4, ctx->d_mean, bytes, hipMemcpyDeviceToHost));
   if (m24) HIP_TRY(ctx, hipMemcpy(m24, ctx->d_m2, bytes, hipMemcpyDeviceToHost));
   return DMT_OK;
@@ -1968,13 +1983,7 @@ int dmt_sync(dmt_ctx* ctx) {
   if (!ctx) return DMT_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  uint32_t flag = 0;
-  HIP_TRY(ctx, hipMemcpy(&flag, ctx->d_counter + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
-  if (flag) {
-    (void)hipMemset(ctx->d_counter + 1, 0, sizeof(uint32_t));
-    return fail(ctx, DMT_ERR_HIP, "a wave gave up waiting for a tile's previous sample chunk (in-launch ordering)");
-  }
-  return DMT_OK;
+  return checkErrorFlag(ctx);
 }
 
 // (re)builds the per-triangle lookup from the host copy of the area-light list
@@ -2105,6 +2114,7 @@ int dmt_kernel_time(dmt_ctx* ctx, double* total_ms, uint64_t* launches, int rese
   if (!ctx) return DMT_ERR_INVALID;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int const rc = checkErrorFlag(ctx)) return rc;  // a time measured on an invalid film is not reported
   for (size_t i = 0; i < ctx->eventsUsed; ++i) {
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));

@@ -1,8 +1,14 @@
-// dmt-megakernel-hip -- command-line driver with the reference's dmt-megakernel surface
-// (examples/triangles/megakernel/main.cu:67-243; flags CC/private/host_utils.cu:39-92):
-//   --width <N> --height <N> --spp <N> --kspp <N> --log-level info|verbose --save-partial
-// plus --max-depth <N> (reference constant 32), --device <ordinal>, --out <dir>, --scene <file.json>, --bvh.
-// Renders the hard-coded cornellBox() scene kspp samples per launch and writes
+// dmt-megakernel-hip -- command-line driver with the reference's two CLI surfaces:
+//   * dmt-megakernel (examples/triangles/megakernel/main.cu:67-243; flags CC/private/host_utils.cu:39-92):
+//       --width <N> --height <N> --spp <N> --kspp <N> --log-level info|verbose --save-partial
+//   * dmt-tracer (cli/CLIManager.cpp:11-36): --device|-d cpu|gpu, --scene|-s <file>, --out|-o <path>, --time|-t,
+//       --help|-h.  `--device cpu` is refused: this build has no CPU renderer (the CPU oracle under oracle/ is test
+//       infrastructure and is never linked into the product).
+// plus --max-depth <N> (reference constant 32), --gpu-ordinal <N>, --bvh, and --gpus <N>: N contexts, one per GPU
+// (ordinals 0..N-1), each rendering the interleaved 8x8 tiles j mod N == rank (dmt_set_partition) concurrently; the N
+// films are disjoint and summed on the host (x + 0: an exact gather).  bench.py's N-process RCCL path is the scalable
+// form of the same partition; --gpus is the single-process form for the CLI.
+// Renders the hard-coded cornellBox() scene (or --scene) kspp samples per launch and writes
 // output-<spp>.png and output-<spp>_sqrt_mse.png next to the executable (or into --out).
 #include <unistd.h>
 
@@ -19,7 +25,11 @@ namespace {
 
 struct Config {  // defaults: CC/public/cuda-core/host_utils.cuh:25-31
   int width = 256, height = 256, spp = 2048, kspp = 4;
-  int maxDepth = 32, device = 0;
+  int maxDepth = 32, device = 0, gpus = 1;
+  std::string deviceKind = "gpu";  // cli/CLIManager.cpp:12-16 (the reference's default is cpu; this build only has gpu)
+  bool timeReport = false;         // --time / -t
+  bool bad = false;                // unknown option / missing value
+  std::string badWhat;
   std::string logLevel = "info", outDir;
   bool savePartial = false;
   std::string scenePath;  // --scene <file.json>: the reference's JSON scene description instead of cornellBox()
@@ -34,6 +44,10 @@ struct Config {  // defaults: CC/public/cuda-core/host_utils.cuh:25-31
     if (kspp <= 0) return "invalid kspp: should be bigger than zero. got " + std::to_string(kspp);
     if (logLevel != "info" && logLevel != "verbose") return "invalid logLevel value. Either info or verbose, got " + logLevel;
     if (maxDepth < 0) return "invalid max-depth";
+    if (bad) return badWhat;
+    if (deviceKind != "cpu" && deviceKind != "gpu") return "--device: wrong argument is not allowed. (cpu or gpu, got " + deviceKind + ")";
+    if (gpus < 1 || gpus > 64) return "invalid --gpus: expected 1..64, got " + std::to_string(gpus);
+    if (device < 0) return "invalid --gpu-ordinal";
     return "";
   }
 };
@@ -48,9 +62,13 @@ void printHelp() {
       "  --log-level <N>   -- Log Verbosity, 'info' or 'verbose'\n"
       "  --save-partial    -- Whether to save images every <kspp> samples\n"
       "  --max-depth <N>   -- Bounce cap (reference: 32)\n"
-      "  --device <N>      -- GPU ordinal\n"
-      "  --out <dir>       -- Output directory (default: the executable's directory)\n"
-      "  --scene <file>    -- JSON scene (camera/film/materials/objects/lights/envlight/transforms/world) or *.pbrt\n"
+      "  --device, -d <cpu|gpu> -- Device used for the rendering (only gpu is built; cpu is refused)\n"
+      "  --gpu-ordinal <N> -- First GPU ordinal (default 0)\n"
+      "  --gpus <N>        -- Partition the frame over N GPUs (ordinals gpu-ordinal .. +N-1), interleaved 8x8 tiles\n"
+      "  --time, -t        -- Measure and report the execution times of key rendering operations\n"
+      "  --out, -o <dir>   -- Output directory (default: the executable's directory)\n"
+      "  --help, -h        -- This text\n"
+      "  --scene, -s <file> -- JSON scene (camera/film/materials/objects/lights/envlight/transforms/world) or *.pbrt\n"
       "                       (PBRT-v4 subset: diffuse materials, triangle meshes, diffuse area lights);\n"
       "                       its resolution, samples and max-depth apply unless given on the command line\n"
       "  --bvh             -- BVH traversal instead of the brute-force triangle loop");
@@ -64,15 +82,19 @@ Config parseArguments(int argc, char** argv) {
     if (a == "--width" && more) c.width = std::atoi(argv[++i]), c.widthSet = true;
     else if (a == "--height" && more) c.height = std::atoi(argv[++i]), c.heightSet = true;
     else if (a == "--spp" && more) c.spp = std::atoi(argv[++i]), c.sppSet = true;
-    else if (a == "--scene" && more) c.scenePath = argv[++i];
+    else if ((a == "--scene" || a == "-s") && more) c.scenePath = argv[++i];
     else if (a == "--bvh") c.bvh = true;
     else if (a == "--kspp" && more) c.kspp = std::atoi(argv[++i]);
     else if (a == "--log-level" && more) c.logLevel = argv[++i];
     else if (a == "--save-partial") c.savePartial = true;
     else if (a == "--max-depth" && more) c.maxDepth = std::atoi(argv[++i]), c.depthSet = true;
-    else if (a == "--device" && more) c.device = std::atoi(argv[++i]);
-    else if (a == "--out" && more) c.outDir = argv[++i];
-    else if (a == "--help") { printHelp(); std::exit(0); }
+    else if ((a == "--device" || a == "-d") && more) c.deviceKind = argv[++i];
+    else if (a == "--gpu-ordinal" && more) c.device = std::atoi(argv[++i]);
+    else if (a == "--gpus" && more) c.gpus = std::atoi(argv[++i]);
+    else if (a == "--time" || a == "-t") c.timeReport = true;
+    else if ((a == "--out" || a == "-o") && more) c.outDir = argv[++i];
+    else if (a == "--help" || a == "-h") { printHelp(); std::exit(0); }
+    else if (!c.bad) c.bad = true, c.badWhat = "Unknown option (or missing value): " + a;  // CLIManager.cpp:52-56
   }
   return c;
 }
@@ -87,16 +109,33 @@ std::string executableDirectory() {
   return slash == std::string::npos ? "." : p.substr(0, slash);
 }
 
+struct Contexts {  // one dmt_ctx per GPU of the run; destroyed on every exit path
+  std::vector<dmt_ctx*> v;
+  ~Contexts() {
+    for (dmt_ctx* c : v)
+      if (c) dmt_ctx_destroy(c);
+  }
+};
+
 int fail(dmt_ctx* ctx, char const* what) {
   std::fprintf(stderr, "%s failed: %s\n", what, dmt_last_error(ctx));
-  if (ctx) dmt_ctx_destroy(ctx);
   return 1;
+}
+
+double msSince(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 }  // namespace
 
 int main(int argc, char** argv) {
   Config cfg = parseArguments(argc, argv);
+  if (cfg.deviceKind == "cpu") {  // the reference's CLI default (CLIManager.cpp:12-16); not part of this build
+    std::fprintf(stderr, "--device cpu: not built.  This is the HIP path of the renderer; it has no CPU fallback "
+                         "(the CPU restatement under oracle/ is test infrastructure).  Use --device gpu.\n");
+    return 1;
+  }
+  auto const tLoad = std::chrono::steady_clock::now();
   dmt_host::JsonScene json;
   if (!cfg.scenePath.empty()) {
     std::string err;
@@ -127,20 +166,41 @@ int main(int argc, char** argv) {
   std::printf("Parsed Configuration:\n - Width:     %d\n - Height:    %d\n - SPP:       %d\n - KSPP:      %d\n - Log Level: %s\n",
               cfg.width, cfg.height, cfg.spp, cfg.kspp, cfg.logLevel.c_str());
   bool const verbose = cfg.logLevel == "verbose";
-
-  dmt_ctx* ctx = nullptr;
-  if (dmt_ctx_create(cfg.device, &ctx) != DMT_OK) return fail(nullptr, "dmt_ctx_create");
   dmt_host::Scene scene = cfg.scenePath.empty() ? dmt_host::cornellBox() : std::move(json.scene);
   scene.camera.width = cfg.width, scene.camera.height = cfg.height, scene.camera.spp = cfg.kspp;
-  if (dmt_host::uploadScene(ctx, scene) != DMT_OK) return fail(ctx, "uploadScene");
-  if (dmt_set_limits(ctx, cfg.maxDepth) != DMT_OK) return fail(ctx, "dmt_set_limits");
-  if (cfg.bvh && dmt_set_accel(ctx, DMT_ACCEL_BVH) != DMT_OK) return fail(ctx, "dmt_set_accel");
+  double const loadMs = msSince(tLoad);
+
+  // one context per GPU; DMT_CLI_SHARE_DEVICE=1 (tests on a one-GPU box) maps all ranks onto --gpu-ordinal
+  auto const tUpload = std::chrono::steady_clock::now();
+  bool const share = std::getenv("DMT_CLI_SHARE_DEVICE") != nullptr;
+  Contexts C;
+  C.v.assign(size_t(cfg.gpus), nullptr);
+  for (int r = 0; r < cfg.gpus; ++r) {
+    if (dmt_ctx_create(share ? cfg.device : cfg.device + r, &C.v[size_t(r)]) != DMT_OK) return fail(nullptr, "dmt_ctx_create");
+    dmt_ctx* ctx = C.v[size_t(r)];
+    if (dmt_host::uploadScene(ctx, scene) != DMT_OK) return fail(ctx, "uploadScene");
+    if (dmt_set_limits(ctx, cfg.maxDepth) != DMT_OK) return fail(ctx, "dmt_set_limits");
+    if (cfg.bvh && dmt_set_accel(ctx, DMT_ACCEL_BVH) != DMT_OK) return fail(ctx, "dmt_set_accel");
+    if (dmt_set_partition(ctx, r, cfg.gpus) != DMT_OK) return fail(ctx, "dmt_set_partition");
+  }
+  double const uploadMs = msSince(tUpload);
 
   std::string const dir = cfg.outDir.empty() ? executableDirectory() : cfg.outDir;
   size_t const pixels = size_t(cfg.width) * size_t(cfg.height);
-  std::vector<float> mean(4 * pixels), m2(4 * pixels);
+  std::vector<float> mean(4 * pixels), m2(4 * pixels), pm, pm2;
+  double downloadMs = 0.0, writeMs = 0.0;
   auto writeOut = [&](int samples) {
-    if (dmt_download_film(ctx, mean.data(), m2.data()) != DMT_OK) return false;
+    auto const t0 = std::chrono::steady_clock::now();
+    if (dmt_download_film(C.v[0], mean.data(), m2.data()) != DMT_OK) return fail(C.v[0], "dmt_download_film"), false;
+    if (cfg.gpus > 1) {  // disjoint tile sets over zero-initialised frames: the sum is an exact gather
+      pm.resize(4 * pixels), pm2.resize(4 * pixels);
+      for (int r = 1; r < cfg.gpus; ++r) {
+        if (dmt_download_film(C.v[size_t(r)], pm.data(), pm2.data()) != DMT_OK) return fail(C.v[size_t(r)], "dmt_download_film"), false;
+        for (size_t i = 0; i < 4 * pixels; ++i) mean[i] += pm[i], m2[i] += pm2[i];
+      }
+    }
+    downloadMs += msSince(t0);
+    auto const t1 = std::chrono::steady_clock::now();
     std::string err;
     std::puts("Writing to file");
     if (!dmt_host::writeMeanAndMSERowMajor(mean.data(), m2.data(), uint32_t(cfg.width), uint32_t(cfg.height),
@@ -148,6 +208,7 @@ int main(int argc, char** argv) {
       std::fprintf(stderr, "%s\n", err.c_str());
       return false;
     }
+    writeMs += msSince(t1);
     return true;
   };
 
@@ -157,18 +218,34 @@ int main(int argc, char** argv) {
   for (int sTot = 0; sTot < cfg.spp; sTot += cfg.kspp) {
     if (verbose) std::printf("Running HIP Kernel (%d)\n", sTot);
     auto const t0 = std::chrono::steady_clock::now();
-    if (dmt_render(ctx, uint32_t(sTot), uint32_t(cfg.kspp), 0, 0, cfg.width, cfg.height) != DMT_OK) return fail(ctx, "dmt_render");
-    if (dmt_sync(ctx) != DMT_OK) return fail(ctx, "dmt_sync");
-    totalMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (dmt_ctx* ctx : C.v)  // asynchronous: all GPUs run their share of this batch concurrently
+      if (dmt_render(ctx, uint32_t(sTot), uint32_t(cfg.kspp), 0, 0, cfg.width, cfg.height) != DMT_OK) return fail(ctx, "dmt_render");
+    for (dmt_ctx* ctx : C.v)
+      if (dmt_sync(ctx) != DMT_OK) return fail(ctx, "dmt_sync");
+    totalMs += msSince(t0);
     ++launches;
-    if (cfg.savePartial && !writeOut(sTot + cfg.kspp)) return fail(ctx, "write");
+    if (cfg.savePartial && !writeOut(sTot + cfg.kspp)) return 1;
   }
-  if (!cfg.savePartial && !writeOut(cfg.spp)) return fail(ctx, "write");
+  if (!cfg.savePartial && !writeOut(cfg.spp)) return 1;
   double const samples = double(pixels) * double(launches) * double(cfg.kspp);
   std::printf("Done! Total Execution Time(excl write file): %llu ms | Average Execution per Kernel launch (%d spp): %llu ms | %.2f Msamples/s\n",
               static_cast<unsigned long long>(totalMs), cfg.kspp, static_cast<unsigned long long>(totalMs / launches),
               samples / (totalMs * 1e3));
+  if (cfg.timeReport) {  // --time: execution times of the key operations (cli/CLIManager.cpp:27-31)
+    double kernelMs = 0.0;
+    uint64_t n = 0;
+    for (dmt_ctx* ctx : C.v) {
+      double ms = 0.0;
+      uint64_t k = 0;
+      if (dmt_kernel_time(ctx, &ms, &k, 1) == DMT_OK && ms > kernelMs) kernelMs = ms, n = k;
+    }
+    std::printf("Timing report:\n - scene load / build:        %10.3f ms\n - context + upload%s: %10.3f ms (%d GPU%s)\n"
+                " - render (launch + sync):    %10.3f ms in %d launch(es) of %d spp\n"
+                " - kernels (HIP events, max over GPUs): %10.3f ms in %llu launch(es)\n"
+                " - film download%s:   %10.3f ms\n - PNG encode + write:       %10.3f ms\n",
+                loadMs, cfg.bvh ? " + BVH build" : "            ", uploadMs, cfg.gpus, cfg.gpus > 1 ? "s" : "", totalMs, launches, cfg.kspp,
+                kernelMs, static_cast<unsigned long long>(n), cfg.gpus > 1 ? " + gather" : "         ", downloadMs, writeMs);
+  }
   std::puts("Cleanup...");
-  dmt_ctx_destroy(ctx);
   return 0;
 }

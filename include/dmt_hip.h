@@ -126,6 +126,7 @@ int dmt_film_clear(dmt_ctx* ctx);
 /* use caller-owned device buffers (width*height float4 each) instead of the context's own */
 int dmt_film_bind(dmt_ctx* ctx, void* d_mean, void* d_m2);
 int dmt_film_device_ptrs(dmt_ctx* ctx, void** d_mean, void** d_m2);
+/* synchronises the stream; DMT_ERR_HIP (and no copy) if a wave of a past launch gave up its ordered fold (see dmt_sync) */
 int dmt_download_film(dmt_ctx* ctx, float* mean4, float* m24);
 
 /* ---- render -------------------------------------------------------------------------------- */
@@ -140,9 +141,13 @@ int dmt_render_stats(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0,
                      uint64_t* stats6);
 /* Diagnostic: dmt_render_stats plus the loop profile of the BVH kernel.  stats16 = the six counters above, then
  * wave-loop iterations x 64 (node steps, leaf steps, shading steps, outer iterations, sample preparations) and the
- * lanes that did work in leaf / shading / preparation steps; node visits that entered no child; one reserved word. */
+ * lanes that did work in leaf / shading / preparation steps; node visits that entered no child; traversal-stack pushes that
+ * went to the global overflow area (entries beyond the LDS part of the stack). */
 int dmt_render_profile(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1,
                        uint64_t* stats16);
+/* waits for the stream; DMT_ERR_HIP if any wave gave up waiting for a tile's previous sample chunk (the in-launch
+ * ordering that makes the film schedule-independent): the film is then invalid.  dmt_download_film and dmt_kernel_time
+ * report the same condition. */
 int dmt_sync(dmt_ctx* ctx);
 /* HIP-event time of the megakernel launches since the last reset (synchronises the stream):
  * total milliseconds and launch count. */

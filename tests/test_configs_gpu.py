@@ -1,0 +1,157 @@
+"""BASELINE.json configs at their EXACT parameters, on the GPU through the C ABI, against the CPU oracle.
+
+  C1  cornellBox, 512 x 512, 64 spp, bounce cap 4
+  C3  the reference's own scenes/sphere.fbx under scenes/veranda_polyhaven_1k.png (committed as data fixtures under
+      tests/golden/c3/), scene description = the reference's scenes/fbx_example.json, 2048 spp, BVH + env-map kernel
+  C5  the 4096 x 4096 frame (one GPU, reduced spp): counts, finiteness, oracle band, sample indices up to 4095
+
+C2 and C4 at full size are exercised by test_parity_gpu.py (test_full_size_invariants, test_bvh_million_triangles)
+and by bench.py's own oracle band.  The oracle runs on row BANDS of the frame so that each test finishes in seconds.
+
+C3 and the FBX units.  sphere.fbx is a Blender export: UnitScaleFactor 1 (centimetres), Z up / -Y front / X right
+(right-handed), one Model with Lcl Scaling 100 over a unit-radius mesh.  The reference's importer
+(src/core/private/core-mesh-parser.cpp:617-687) converts to centimetres (a no-op for this file), converts the axis
+system with FbxAxisSystem::ConvertScene and bakes the node's GLOBAL transform into the vertices -- i.e. it yields a
+sphere of radius 100 scene units.  fbx_example.json places it at (0, 2, -1) with the camera at the origin, so taken
+literally the camera sits INSIDE the sphere (the importer carries a "TODO check if correct. if not, switch to metres").
+Both readings are tested: `fbx_example_literal.json` (the reference's file with only the env-map name changed from the
+non-existent .exr to the .png that ships beside it) and `c3_sphere_veranda.json` (the same scene with the object's
+transform scaled by 0.01, the metres reading: the sphere is seen from outside under the veranda map, which is the
+"NEE + MIS path" BASELINE config 3 names).  The SDK's axis conversion is not reproduced: for a mesh whose node has no
+rotation or translation it is an orthogonal map about the mesh origin, and what the SDK does on a handedness change
+cannot be checked without the SDK.  Parity of this config is oracle <-> HIP on identical arrays (unpinned by the
+reference: its CPU renderer cannot be built here and ships no image of this scene).
+"""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, film_rmse
+
+pytestmark = pytest.mark.gpu
+
+RMSE_TOL = 1e-3  # north_star / BASELINE.json
+
+
+def _band_rows(height, nrows, nbands):
+    """`nbands` bands of `nrows` rows spread evenly over the frame."""
+    out = []
+    for b in range(nbands):
+        y0 = int((b + 0.5) * height / nbands) - nrows // 2
+        out.append((max(0, y0), min(height, y0 + nrows)))
+    return out
+
+
+def test_c1_cornell_512_64spp_4bounces(renderer, O):
+    """BASELINE configs[0] at its exact parameters."""
+    w = h = 512
+    spp, depth = 64, 4
+    scene = O.cornell_box(w, h)
+    renderer.upload_scene(scene)
+    renderer.set_limits(depth)
+    renderer.set_accel(0)
+    renderer.set_partition(0, 1)
+    renderer.film_clear()
+    renderer.render(spp)
+    renderer.sync()
+    mean, m2 = renderer.download_film()
+    assert np.isfinite(mean).all() and np.isfinite(m2).all()
+    assert np.all(m2[..., 3] == spp) and np.all(mean[..., 3] == 0) and (m2[..., :3] >= 0).all()
+    for y0, y1 in _band_rows(h, 8, 4):       # 4 bands x 8 rows x 512 px x 64 spp = 1 M oracle samples
+        rmean, rm2 = O.render(scene, spp, max_depth=depth, region=(0, y0, w, y1))
+        rmse = film_rmse(mean[y0:y1], rmean[y0:y1])
+        assert rmse < 1e-4, (y0, rmse)       # observed ~1e-6; tolerance of the config: 1e-3
+        assert np.array_equal(m2[y0:y1, :, 3], rm2[y0:y1, :, 3])
+
+
+def _load_c3(pkg, O, name):
+    hs = pkg.host_scene.load_json(GOLDEN / "c3" / name)
+    osc = O.Scene(hs.xs, hs.ys, hs.zs, hs.mat_id, hs.bsdfs, hs.lights, hs.inf_lights, hs.camera)
+    osc.set_envmap(hs.env_rgb)
+    return hs, osc
+
+
+def test_c3_sphere_fbx_veranda_2048spp(renderer, pkg, O):
+    """BASELINE configs[2] on its named assets, 256 x 256 (the JSON's film), 2048 spp, BVH + env-map kernel."""
+    hs, osc = _load_c3(pkg, O, "c3_sphere_veranda.json")
+    assert hs.spp == 2048 and hs.max_depth == 12 and hs.env_rgb.shape == (512, 1024, 3) and hs.tri_count == 480
+    w, h = hs.width, hs.height
+    renderer.upload_scene(hs)
+    renderer.set_limits(hs.max_depth)
+    renderer.set_accel(1)
+    renderer.set_partition(0, 1)
+    try:
+        renderer.film_clear()
+        renderer.render(hs.spp)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
+        # brute-force kernel on the same scene: bit-identical film (BVH equivalence contract)
+        renderer.set_accel(0)
+        renderer.film_clear()
+        renderer.render(hs.spp, region=(0, 120, w, 136))
+        renderer.sync()
+        bmean, bm2 = renderer.download_film()
+    finally:
+        renderer.set_accel(0)
+        renderer.clear_envmap()
+    assert np.isfinite(mean).all() and np.all(m2[..., 3] == hs.spp)
+    assert np.array_equal(mean[120:136], bmean[120:136]) and np.array_equal(m2[120:136], bm2[120:136])
+    scale = float(mean[..., :3].mean())
+    assert scale > 0.1                       # the veranda is visible around the sphere
+    for y0, y1 in _band_rows(h, 2, 4):       # rows through background, sphere rim and sphere centre
+        om, om2 = O.render(osc, hs.spp, max_depth=hs.max_depth, region=(0, y0, w, y1), threads=16)[:2]
+        assert np.array_equal(m2[y0:y1, :, 3], om2[y0:y1, :, 3])
+        rmse = film_rmse(mean[y0:y1], om[y0:y1])
+        assert rmse < RMSE_TOL * max(1.0, scale), (y0, rmse)
+
+
+def test_c3_literal_scene_camera_inside_the_sphere(renderer, pkg, O):
+    """The reference's fbx_example.json read literally (radius-100 sphere around the camera): every camera ray hits the
+    mesh, the env map is only reached through NEE shadow rays that the closed sphere blocks."""
+    hs, osc = _load_c3(pkg, O, "fbx_example_literal.json")
+    w, h = hs.width, hs.height
+    spp = 64
+    renderer.upload_scene(hs)
+    renderer.set_limits(hs.max_depth)
+    renderer.set_accel(1)
+    renderer.set_partition(0, 1)
+    try:
+        renderer.film_clear()
+        renderer.render(spp)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
+    finally:
+        renderer.set_accel(0)
+        renderer.clear_envmap()
+    y0, y1 = 100, 116
+    om, om2 = O.render(osc, spp, max_depth=hs.max_depth, region=(0, y0, w, y1), threads=16)[:2]
+    assert np.array_equal(m2[y0:y1, :, 3], om2[y0:y1, :, 3])
+    assert film_rmse(mean[y0:y1], om[y0:y1]) < RMSE_TOL
+
+
+def test_c5_frame_4096_reduced_spp(renderer, O):
+    """BASELINE configs[4]'s frame on one GPU: 4096 x 4096, samples 4092..4095 (the last sample indices of the
+    4096-spp run: largest Halton indices of the config), cap 8."""
+    w = h = 4096
+    s0, spp, depth = 4092, 4, 8
+    scene = O.cornell_box(w, h)
+    renderer.upload_scene(scene)
+    renderer.set_limits(depth)
+    renderer.set_accel(0)
+    renderer.set_partition(0, 1)
+    renderer.film_clear()
+    renderer.render(spp, sample_offset=s0)
+    renderer.sync()
+    mean, m2 = renderer.download_film()
+    assert mean.shape == (h, w, 4)
+    assert np.isfinite(mean).all() and np.isfinite(m2).all()
+    assert np.all(m2[..., 3] == spp) and np.all(mean[..., 3] == 0) and (m2[..., :3] >= 0).all()
+    for y0, y1 in [(0, 2), (2047, 2049), (4094, 4096)]:
+        rmean, rm2 = O.render(scene, spp, max_depth=depth, region=(0, y0, w, y1), sample_offset=s0)
+        assert film_rmse(mean[y0:y1], rmean[y0:y1]) < 1e-4, y0
+        assert np.array_equal(m2[y0:y1, :, 3], rm2[y0:y1, :, 3])
+    # the film of a region-limited second pass continues the first one exactly (resumable at this size too)
+    renderer.render(2, sample_offset=4090, region=(4000, 4000, 4096, 4096))
+    renderer.sync()
+    _, m2b = renderer.download_film()
+    assert np.all(m2b[4000:, 4000:, 3] == spp + 2) and np.all(m2b[:4000, :, 3] == spp)
+    renderer.film_clear()

@@ -176,3 +176,31 @@ def test_envmap_oracle_properties(O):
     e = O.envmap_eval(img, q, r["wi"])
     flat = img.reshape(-1, 3)
     assert all((flat == row).all(axis=1).any() for row in e["Le"][:64])
+
+
+def test_cli_surface_without_a_gpu(tmp_path):
+    """Flags of the reference's two CLIs (CC/private/host_utils.cu:39-92, cli/CLIManager.cpp:11-36) as far as they can be
+    checked without a GPU: help text lists them, `--device cpu` is refused loudly (no CPU renderer in the product),
+    unknown options and out-of-set values are rejected before anything runs."""
+    import subprocess
+    from pathlib import Path
+    exe = Path(__file__).resolve().parent.parent / "cuda-optix-pathtracing_amd" / "host" / "dmt-megakernel-hip"
+    assert exe.exists(), "run __graft_entry__.build()"
+    run = lambda *a: subprocess.run([str(exe), *a], capture_output=True, text=True, timeout=60)
+    h = run("-h")
+    assert h.returncode == 0
+    for flag in ("--width", "--height", "--spp", "--kspp", "--log-level", "--save-partial", "--device, -d", "--scene, -s",
+                 "--out, -o", "--time, -t", "--help, -h", "--gpus", "--max-depth"):
+        assert flag in h.stdout, flag
+    assert run("--help").stdout == h.stdout
+    c = run("--device", "cpu")
+    assert c.returncode == 1 and "not built" in c.stderr and "no CPU fallback" in c.stderr
+    assert run("-d", "cpu").returncode == 1
+    b = run("-d", "tpu")
+    assert b.returncode == 1 and "wrong argument is not allowed" in b.stderr
+    u = run("--no-such-flag")
+    assert u.returncode == 1 and "Unknown option" in u.stderr
+    g = run("--gpus", "0")
+    assert g.returncode == 1 and "invalid --gpus" in g.stderr
+    m = run("-s", str(tmp_path / "missing.json"), "-d", "gpu")
+    assert m.returncode == 1 and "cannot open" in m.stderr

@@ -176,3 +176,31 @@ def test_json_scene_with_fbx_object(pkg):
     got = np.stack([s.xs[2:, :3], s.ys[2:, :3], s.zs[2:, :3]], -1)   # [tri, vertex, xyz]
     assert np.abs(got - moved).max() < 1e-6
     assert s.env_rgb is not None and s.lights.shape[0] == 1 and s.max_depth == 8
+
+
+def test_c3_fbx_reader_on_the_reference_asset(pkg):
+    """sphere.fbx through the binary reader: 480 triangles, closed, radius 100 file units (Lcl Scaling 100 x unit mesh)."""
+    T = pkg.host_scene.read_fbx(GOLDEN / "c3" / "sphere.fbx")
+    assert T.shape == (480, 3, 3)
+    r = np.linalg.norm(T.reshape(-1, 3), axis=1)
+    assert abs(r.max() - 100.0) < 1e-3 and r.min() > 55.0
+    # closed: every undirected edge is shared by exactly two triangles
+    V, inv = np.unique(np.round(T.reshape(-1, 3), 3), axis=0, return_inverse=True)
+    assert len(V) == 242
+    F = inv.reshape(-1, 3)
+    e = np.sort(np.concatenate([F[:, [0, 1]], F[:, [1, 2]], F[:, [2, 0]]]), axis=1)
+    _, counts = np.unique(e, axis=0, return_counts=True)
+    assert np.all(counts == 2)
+
+
+def test_c3_scene_files_load(pkg):
+    """BASELINE configs[2] fixtures: the reference's fbx_example.json (literal, env-map name fixed) and its metres
+    reading both load; same mesh, 100x apart, same veranda map (see tests/test_configs_gpu.py for the GPU renders)."""
+    lit = pkg.host_scene.load_json(GOLDEN / "c3" / "fbx_example_literal.json")
+    met = pkg.host_scene.load_json(GOLDEN / "c3" / "c3_sphere_veranda.json")
+    assert lit.tri_count == met.tri_count == 480 and lit.spp == 32 and met.spp == 2048 and lit.max_depth == met.max_depth == 12
+    assert lit.env_rgb.shape == (512, 1024, 3) and np.array_equal(lit.env_rgb, met.env_rgb)
+    c = np.array([0, 2, -1], np.float32)
+    P = lambda s: np.stack([s.xs[:, :3], s.ys[:, :3], s.zs[:, :3]], -1).reshape(-1, 3) - c
+    assert np.allclose(P(lit), 100 * P(met), rtol=1e-5, atol=1e-4)
+    assert abs(np.linalg.norm(P(met), axis=1).max() - 1.0) < 1e-5

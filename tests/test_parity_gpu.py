@@ -360,6 +360,51 @@ def test_tile_partition_is_exact(renderer, O):
     assert np.array_equal(sum(p[1] for p in parts), full[1])
 
 
+@pytest.mark.parametrize("accel", [0, 1])
+def test_concurrent_contexts_partition_is_exact(renderer, pkg, O, accel):
+    """Multi-GPU rehearsal on one device: one context per rank (dmt_set_partition(r, W)), each with its OWN stream and
+    film, launched back to back without synchronising in between, so their persistent kernels, work counters, tile
+    counters and staging areas are live at the same time.  Each launch is sized to a fraction of the machine (items <
+    resident waves), so the kernels really co-reside.  Sum of the films == the single-context film, bit for bit; each
+    pixel is owned by exactly one rank; repeated with several passes (resumable films per rank)."""
+    W = 3
+    w, h, spp = 256, 192, 16
+    scene = O.cornell_box(w, h) if accel == 0 else pkg.host_scene.random_triangle_scene(5000, width=w, height=h)
+    renderer.upload_scene(scene)
+    renderer.set_limits(8)
+    renderer.set_accel(accel)
+    renderer.set_partition(0, 1)
+    renderer.film_clear()
+    for k in range(2):
+        renderer.render(spp, sample_offset=k * spp)
+    renderer.sync()
+    full = renderer.download_film()
+    renderer.set_accel(0)
+    ranks = [pkg.Renderer(0) for _ in range(W)]
+    try:
+        for r, ctx in enumerate(ranks):
+            ctx.upload_scene(scene)
+            ctx.set_limits(8)
+            ctx.set_accel(accel)
+            ctx.set_partition(r, W)
+            ctx.film_clear()
+        for k in range(2):
+            for ctx in ranks:                      # asynchronous launches on W different streams
+                ctx.render(spp, sample_offset=k * spp)
+        for ctx in ranks:
+            ctx.sync()                             # raises if any wave gave up its ordered fold
+        parts = [ctx.download_film() for ctx in ranks]
+    finally:
+        for ctx in ranks:
+            ctx.close()
+    counts = sum(p[1][..., 3] for p in parts)
+    assert np.all(counts == 2 * spp)
+    for r in range(W):
+        assert np.array_equal(parts[r][1][..., 3] > 0, pkg.multigpu.owned_pixel_mask(w, h, r, W))
+    assert np.array_equal(sum(p[0] for p in parts), full[0])
+    assert np.array_equal(sum(p[1] for p in parts), full[1])
+
+
 def test_region_split_is_exact(renderer, O):
     _load_cornell(renderer, O, 96, 80)
     renderer.render(4)
@@ -458,33 +503,62 @@ def test_bvh_film_bit_exact_vs_brute_force(renderer, pkg, O):
 
 
 def test_bvh_million_triangles(renderer, pkg, O):
-    """BASELINE config 4 scene (1 M random triangles): BVH == brute force on a few tiles (brute force
-    costs 1 M tests per ray, so only 4 tiles x 1 spp), and vs the CPU oracle on 32 camera rays."""
+    """BASELINE config 4 scene (1 M random triangles): BVH == brute force, bit for bit, on two 64 x 64 windows x 4 spp
+    at the config's bounce cap of 8 (brute force costs 1 M tests per ray: ~2e11 tests), and vs the CPU oracle on 32
+    camera rays."""
     scene = pkg.host_scene.random_triangle_scene(1_000_000, width=1024, height=1024)
     assert pkg.bvh_validate(scene.xs, scene.ys, scene.zs)["ok"]
     renderer.upload_scene(scene)
-    renderer.set_limits(3)
-    region = (496, 504, 528, 512)               # 4 tiles in the middle of the frame
-    films = []
-    for mode in (0, 1):
-        renderer.set_accel(mode)
-        renderer.film_clear()
-        renderer.render(1, region=region)
-        films.append(renderer.download_film())
-    assert np.array_equal(films[0][0], films[1][0]) and np.array_equal(films[0][1], films[1][1])
-    assert np.all(films[1][1][504:512, 496:528, 3] == 1)
+    renderer.set_limits(8)
+    for region in ((480, 480, 544, 544), (3, 950, 67, 1014)):   # centre of the frame; a window off the tile grid near a corner
+        films = []
+        for mode in (0, 1):
+            renderer.set_accel(mode)
+            renderer.film_clear()
+            renderer.render(4, region=region)
+            renderer.sync()
+            films.append(renderer.download_film())
+        assert np.array_equal(films[0][0], films[1][0]) and np.array_equal(films[0][1], films[1][1])
+        x0, y0, x1, y1 = region
+        assert np.all(films[1][1][y0:y1, x0:x1, 3] == 4) and films[1][1][..., 3].sum() == 4 * 64 * 64
+        assert films[1][0][..., :3].max() > 0
     o, d = _rays(32, 99)
     o[:] = 0
     ai, at = renderer.test_closest_hit(o, d)            # accel still BVH
     oi, ot = O.closest_hit(scene.xs, scene.ys, scene.zs, o, d)
     assert np.array_equal(ai, oi)
     # a larger BVH-only render stays finite and fully sampled
-    renderer.set_limits(8)
     renderer.film_clear()
     renderer.render(4, region=(256, 256, 768, 768))
+    renderer.sync()
     mean, m2 = renderer.download_film()
     assert np.isfinite(mean).all() and np.all(m2[256:768, 256:768, 3] == 4)
     renderer.set_accel(0)
+
+
+def test_bvh_overflow_stack_variant(renderer):
+    """The traversal stack keeps 16 entries per lane in LDS and the rest in a global overflow area that ordinary scenes
+    rarely reach.  csrc/variants/libdmt_hip_stack2.so is the same library compiled with 2 LDS entries: every non-trivial
+    traversal then runs through the overflow path.  Closest hits and whole films must still equal brute force bit for
+    bit, and the device counters must show that overflow pushes happened.  Runs in a subprocess (the library is
+    selected at load time through DMT_HIP_LIB)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    lib = root / "cuda-optix-pathtracing_amd" / "csrc" / "variants" / "libdmt_hip_stack2.so"
+    assert lib.exists(), f"{lib} is missing: run __graft_entry__.build()"
+    env = dict(os.environ, DMT_HIP_LIB=str(lib))
+    p = subprocess.run([sys.executable, str(root / "tests" / "_bvh_worker.py")], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["lib"] == str(lib)
+    assert out["closest_equal"] and out["film_equal"], out
+    assert out["hit_share"] > 0.02 and out["film_max"] > 0
+    assert out["overflow_pushes"] > 0.05 * out["node_visits"], out      # the overflow path really ran
+    # the default build on the same scene: the 16 LDS entries suffice (the counter is the same code)
+    assert (root / "cuda-optix-pathtracing_amd" / "csrc" / "libdmt_hip.so").exists()
 
 
 def test_row_band_scheduling_is_bit_exact(pkg, O, monkeypatch):
@@ -631,6 +705,27 @@ def test_envmap_clear_restores_constant_environment(renderer, O):
     again = renderer.download_film()
     assert np.array_equal(base[0], again[0]) and np.array_equal(base[1], again[1])
     assert not np.array_equal(base[0], withmap[0])
+
+
+def test_cli_time_report_and_gpus_partition(tmp_path):
+    """cli/CLIManager.cpp's --time / short options, and --gpus N: N contexts render interleaved tile sets concurrently
+    and the gathered image equals the one-context image byte for byte (here both contexts share the box's one GPU)."""
+    import os
+    import subprocess
+    from pathlib import Path
+    exe = Path(__file__).resolve().parent.parent / "cuda-optix-pathtracing_amd" / "host" / "dmt-megakernel-hip"
+    args = ["--width", "72", "--height", "56", "--spp", "16", "--kspp", "8", "--max-depth", "8", "-d", "gpu", "-t"]
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(), two.mkdir()
+    r1 = subprocess.run([str(exe), *args, "-o", str(one)], capture_output=True, text=True, timeout=120)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    assert "Timing report:" in r1.stdout and "kernels (HIP events" in r1.stdout and "PNG encode + write" in r1.stdout
+    r2 = subprocess.run([str(exe), *args, "--gpus", "3", "-o", str(two)], capture_output=True, text=True, timeout=120,
+                        env=dict(os.environ, DMT_CLI_SHARE_DEVICE="1"))
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert "(3 GPUs)" in r2.stdout
+    for name in ("output-16.png", "output-16_sqrt_mse.png"):
+        assert (one / name).read_bytes() == (two / name).read_bytes(), name
 
 
 # ---------------------------------------------------------------------------------------------
