@@ -2,7 +2,7 @@
 //   * dmt-megakernel (examples/triangles/megakernel/main.cu:67-243; flags CC/private/host_utils.cu:39-92):
 //       --width <N> --height <N> --spp <N> --kspp <N> --log-level info|verbose --save-partial
 //   * dmt-tracer (cli/CLIManager.cpp:11-36): --device|-d cpu|gpu, --scene|-s <file>, --out|-o <path>, --time|-t,
-//       --help|-h.  `--device cpu` is refused: this build has no CPU renderer (the CPU oracle under oracle/ is test
+//       --help|-h.  `--device cpu` is refused: this build has no CPU renderer (the CPU restatement used by the tests is test
 //       infrastructure and is never linked into the product).
 // plus --max-depth <N> (reference constant 32), --gpu-ordinal <N>, --bvh, and --gpus <N>: N contexts, one per GPU
 // (ordinals 0..N-1), each rendering the interleaved 8x8 tiles j mod N == rank (dmt_set_partition) concurrently; the N
@@ -132,7 +132,7 @@ int main(int argc, char** argv) {
   Config cfg = parseArguments(argc, argv);
   if (cfg.deviceKind == "cpu") {  // the reference's CLI default (CLIManager.cpp:12-16); not part of this build
     std::fprintf(stderr, "--device cpu: not built.  This is the HIP path of the renderer; it has no CPU fallback "
-                         "(the CPU restatement under oracle/ is test infrastructure).  Use --device gpu.\n");
+                         "(the CPU restatement used by the tests is not part of the product).  Use --device gpu.\n");
     return 1;
   }
   auto const tLoad = std::chrono::steady_clock::now();
