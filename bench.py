@@ -71,8 +71,8 @@ WORKLOADS = {
     "cornell_4096x4096_4096spp_8bounces": (4096, 4096, 4096, 8, "cornell"),
 }
 RANDOM_SCENE_TRIANGLES = {"random1M": 1_000_000, "random16M": 16_000_000}
-BVH_NODE_BYTES = 128           # csrc/bvh.hpp Bvh4Node
-BVH_LEAF_BYTES_PER_TRI = 64    # csrc/bvh.hpp TriPair: 128 B per pair
+BVH_NODE_BYTES = 64            # csrc/bvh.hpp Bvh4Node: one 64-byte sector (48 bytes read)
+BVH_LEAF_BYTES_PER_TRI = 40    # csrc/bvh.hpp TriPair: 80 B per pair
 DEFAULT_WORKLOAD = "cornell_1024x1024_1024spp_8bounces"
 C1_WORKLOAD = "cornell_512x512_64spp_4bounces"
 

@@ -1,17 +1,27 @@
-// bvh.hpp -- 4-wide BVH: node layout (shared host/device) and the host builder.
+// bvh.hpp -- 4-wide BVH: node / leaf layout (shared host/device) and the host builder.
 //
-// Semantics follow the reference's only BVH, the CPU renderer's: binned-SAH splits on
-// the longest centroid axis, small leaves, wide nodes obtained by collapsing binary splits
-// (src/core/private/core-bvh-builder.cpp:58-223 builds an 8-ary tree the same way, 16-128 bins,
-// leaves <= 7).  Layout and traversal are designed for gfx950 instead of AVX2: 128-byte nodes read
-// as eight 16-byte per-lane loads, child boxes as SoA so a lane tests the four children with plain
-// VALU min/max, leaves of <= 2 triangles stored as one interleaved pair.
+// Semantics follow the reference's only BVH, the CPU renderer's: binned-SAH splits,
+// small leaves, wide nodes obtained by collapsing binary splits (src/core/private/core-bvh-builder.cpp:58-223
+// builds an 8-ary tree the same way, 16-128 bins, leaves <= 7).  The LAYOUT is designed for what bounds per-lane
+// traversal on gfx950: the vector-memory front end.  tools/ubench/gather.hip (a dependent per-lane gather like a
+// traversal's) measures, chip-wide, for records served by L2:
+//     128-byte record, 7 x 16-byte loads per lane     88 G lane-steps/s   (round 1's node)
+//     128-byte record, 5 loads                       121                  (round 1's triangle pair)
+//      64-byte slot, 4 loads                         214
+//      64-byte slot, 3 loads                         290                  (this node)
+//      80-byte record, 5 loads                       178                  (this triangle pair)
+// i.e. a step costs ~max(0.7 x loads, 64-byte sectors touched x 64 / 26) clocks of the CU's L1 path, whatever the
+// occupancy; round 1's kernel ran at 75 % of the first two rates.  So:
+//   * Bvh4Node = 48 bytes of payload in a 64-byte slot (one sector, three loads): the children's boxes are
+//     quantised to 8 bits per plane relative to the node's own box (origin + power-of-two scale per axis) and child
+//     references are implicit (inner children contiguous from childBase, leaves contiguous from leafBase).
+//   * TriPair = 80 bytes (five loads): two triangles interleaved component by component for packed math.
 //
-// Correctness contract (tests/test_parity_gpu.py::test_bvh_*): traversal returns exactly the
-// brute-force closest hit -- same triangle (lowest ORIGINAL index on equal t) and bit-identical
-// (t,u,v), because the same Moeller-Trumbore routine runs on the same triangle record -- and the same
-// any-hit answer.  Boxes are padded so that a ray accepted by the triangle test (which has its own
-// 1e-7 barycentric slack and rounding) can never be culled by a box test.
+// Correctness contract (tests/test_parity_gpu.py::test_bvh_*): traversal returns exactly the brute-force closest hit
+// -- same triangle (lowest ORIGINAL index on equal t) and bit-identical (t,u,v), because the same Moeller-Trumbore
+// routine runs on the same fp32 triangle record -- and the same any-hit answer.  Boxes only cull: triangle boxes are
+// padded so that a ray the triangle test accepts can never be culled, and quantisation only ever GROWS a box (lo rounded
+// down, hi rounded up, in exact arithmetic: origin and scale are floats, q * scale is exact).
 #pragma once
 
 #include <stdint.h>
@@ -34,29 +44,50 @@ constexpr int kBvhMaxDepth = 48;   // depth bound (binary levels, hence also 4-w
 constexpr int kBvhLdsStack = DMT_BVH_LDS_STACK;   // traversal stack entries kept in LDS per lane
 constexpr int kBvhOverflowStack = 3 * kBvhMaxDepth - kBvhLdsStack;  // the rest, per lane, in global memory
 
-// child reference: kBvhEmpty | inner node index | kBvhLeafFlag | (count-1) << 28 | first
-// (builder: count triangles from slot `first`; device: count triangle PAIRS from pair `first`)
-inline uint32_t bvhLeafRef(uint32_t first, uint32_t count) { return kBvhLeafFlag | ((count - 1u) << 28) | first; }
+// traversal-stack entry / current position: kBvhEmpty | inner node index | kBvhLeafFlag | pair index
+inline uint32_t bvhLeafRef(uint32_t pair) { return kBvhLeafFlag | pair; }
 
 // Leaf storage on the device: two triangles interleaved component by component, so that the 16-byte loads
-// deliver (first, second) register pairs ready for packed math; one 128-byte cache line per pair.  A leaf of
-// 1-4 triangles is 1-2 consecutive pairs; an odd leaf repeats its last triangle (same original index, so the
-// repeated test can never win the tie-break against itself).
-struct TriPair {  // 128 B
+// deliver (first, second) register pairs ready for packed math.  A leaf is ONE pair; a one-triangle leaf repeats its
+// triangle (same original index, so the repeated test can never win the tie-break against itself).
+struct TriPair {  // 80 B = five 16-byte loads
   float p0x[2], p0y[2], p0z[2], e0x[2], e0y[2], e0z[2], e1x[2], e1y[2], e1z[2];
   uint32_t orig[2];  // ORIGINAL triangle indices (brute-force tie-break, shading)
-  uint32_t pad[12];
 };
-static_assert(sizeof(TriPair) == 128, "pair size");
+static_assert(sizeof(TriPair) == 80, "pair size");
 
-struct Bvh4Node {  // 128 B
-  float minx[4], miny[4], minz[4];
-  float maxx[4], maxy[4], maxz[4];
-  uint32_t child[4];
+// Inner node.  Child k (k < count) has the box  [origin + qlo_k * scale, origin + qhi_k * scale]  per axis, with
+// scale_axis = 2^(exp_axis - 127) and the q's the k-th BYTES of the six plane words.  Children 0 .. inner-1 are the inner
+// nodes childBase + k; children inner .. count-1 are the leaves (triangle pairs) leafBase + (k - inner).
+struct Bvh4Node {  // 64-byte slot, 48 bytes read (three 16-byte loads)
+  float ox, oy, oz;       // quantisation origin = lower corner of the node's box
+  uint32_t meta;          // byte 0-2: biased power-of-two exponent of the x / y / z scale; byte 3: inner | count << 4
+  uint32_t childBase;     // first inner child
+  uint32_t leafBase;      // first leaf child (pair index)
+  uint32_t qlox, qhix;    // byte k: child k's quantised planes
+  uint32_t qloy, qhiy, qloz, qhiz;
   uint32_t pad[4];
 };
-static_assert(sizeof(Bvh4Node) == 128, "node size");
+static_assert(sizeof(Bvh4Node) == 64, "node size");
 
+inline int bvhNodeInner(Bvh4Node const& n) { return int((n.meta >> 24) & 0xFu); }
+inline int bvhNodeCount(Bvh4Node const& n) { return int((n.meta >> 28) & 0xFu); }
+inline float bvhNodeScale(Bvh4Node const& n, int axis) {
+  uint32_t const bits = ((n.meta >> (8 * axis)) & 0xFFu) << 23;
+  float f;
+  std::memcpy(&f, &bits, 4);
+  return f;
+}
+// decoded box of child k (host side: validation and tests; the device never forms the planes, see bvh_device.hpp)
+inline void bvhChildBox(Bvh4Node const& n, int k, float lo[3], float hi[3]) {
+  uint32_t const ql[3] = {n.qlox, n.qloy, n.qloz}, qh[3] = {n.qhix, n.qhiy, n.qhiz};
+  float const o[3] = {n.ox, n.oy, n.oz};
+  for (int a = 0; a < 3; ++a) {
+    float const s = bvhNodeScale(n, a);
+    lo[a] = o[a] + float((ql[a] >> (8 * k)) & 0xFFu) * s;
+    hi[a] = o[a] + float((qh[a] >> (8 * k)) & 0xFFu) * s;
+  }
+}
 
 namespace bvh_build {
 
@@ -186,12 +217,54 @@ struct Builder {
 
 struct Result {
   std::vector<Bvh4Node> nodes;
-  std::vector<uint32_t> slotToTri;  // triangle stored in slot s (leaf order)
+  std::vector<uint32_t> pairTris;  // two ORIGINAL triangle indices per leaf pair (the second repeats the first in a one-triangle leaf)
   int depth = 0;
 };
 
+// Quantise the boxes of `nk` children (inner children first) into node `nd`.  Exact-arithmetic guarantee: the decoded
+// box encloses the given one.
+inline void encodeNode(Bvh4Node& nd, Box const* kid, int nk, int nInner) {
+  std::memset(&nd, 0, sizeof(nd));
+  Box all;
+  all.reset();
+  for (int k = 0; k < nk; ++k) all.grow(kid[k]);
+  uint32_t ebytes[3] = {127, 127, 127};
+  float org[3] = {0, 0, 0};
+  double scale[3] = {1, 1, 1};
+  for (int a = 0; a < 3 && nk > 0; ++a) {
+    org[a] = all.lo[a];
+    double const ext = double(all.hi[a]) - double(all.lo[a]);
+    int e = -126;
+    if (ext > 0.0) {
+      int fe;
+      (void)std::frexp(ext / 255.0, &fe);  // ext / 255 = m * 2^fe, m in [0.5, 1)  ->  2^fe >= ext / 255
+      e = fe;
+    }
+    e = std::min(std::max(e, -126), 127);
+    while (e < 127 && std::ldexp(255.0, e) < ext) ++e;
+    ebytes[a] = uint32_t(e + 127);
+    scale[a] = std::ldexp(1.0, e);
+  }
+  nd.ox = org[0], nd.oy = org[1], nd.oz = org[2];
+  nd.meta = ebytes[0] | (ebytes[1] << 8) | (ebytes[2] << 16) | (uint32_t(nInner) << 24) | (uint32_t(nk) << 28);
+  uint32_t* const qlo[3] = {&nd.qlox, &nd.qloy, &nd.qloz};
+  uint32_t* const qhi[3] = {&nd.qhix, &nd.qhiy, &nd.qhiz};
+  for (int k = 0; k < 4; ++k)
+    for (int a = 0; a < 3; ++a) {
+      uint32_t l = 255, h = 0;  // empty slot: inverted box (and masked by count on the device)
+      if (k < nk) {
+        double const fl = std::floor((double(kid[k].lo[a]) - double(org[a])) / scale[a]);
+        double const fh = std::ceil((double(kid[k].hi[a]) - double(org[a])) / scale[a]);
+        l = uint32_t(std::min(std::max(fl, 0.0), 255.0));
+        h = uint32_t(std::min(std::max(fh, 0.0), 255.0));
+      }
+      *qlo[a] |= l << (8 * k), *qhi[a] |= h << (8 * k);
+    }
+}
+
 // xs/ys/zs: the reference's SoA (4 floats per triangle: c0, c1, c2, pad)
 inline Result build(float const* xs, float const* ys, float const* zs, uint32_t n) {
+  static_assert(kBvhMaxLeafTris == 2, "a leaf is one triangle pair");
   Result out;
   Builder b;
   b.triBox.resize(n), b.centroid.resize(3 * size_t(n)), b.order.resize(n);
@@ -213,73 +286,82 @@ inline Result build(float const* xs, float const* ys, float const* zs, uint32_t 
     for (int a = 0; a < 3; ++a) b.centroid[3 * size_t(i) + a] = 0.5f * (bx.lo[a] + bx.hi[a]);
     b.order[i] = i;
   }
-  if (n == 0) {  // a root whose children are all empty
+  if (n == 0) {  // a root without children
     Bvh4Node root;
-    for (int k = 0; k < 4; ++k) {
-      root.minx[k] = root.miny[k] = root.minz[k] = std::numeric_limits<float>::infinity();
-      root.maxx[k] = root.maxy[k] = root.maxz[k] = -std::numeric_limits<float>::infinity();
-      root.child[k] = kBvhEmpty, root.pad[k] = 0;
-    }
+    encodeNode(root, nullptr, 0, 0);
     out.nodes.push_back(root);
     return out;
   }
   b.nodes.reserve(size_t(n));
   int const root2 = b.build(0, n, kBvhMaxDepth);
-  out.slotToTri = b.order;
 
-  // collapse binary splits into 4-wide nodes: repeatedly open the inner child of largest area
-  struct Work {
-    int node2;
-    uint32_t node4;
-    int depth;
+  // collapse binary splits into 4-wide nodes: repeatedly open the inner child of largest area.  A node's inner
+  // children get CONSECUTIVE node indices (implicit child references), processed breadth-first so that index order
+  // is also level order of each subtree's top.
+  struct Wide {
+    int kids[4];  // binary node ids, inner children first
+    int nk = 0, nInner = 0;
+    int depth = 1;
   };
-  std::vector<Work> stack;
-  out.nodes.emplace_back();
-  stack.push_back({root2, 0u, 1});
-  while (!stack.empty()) {
-    Work const w = stack.back();
-    stack.pop_back();
-    out.depth = std::max(out.depth, w.depth);
+  std::vector<Wide> wide;
+  wide.emplace_back();
+  std::vector<int> source;  // binary node each wide node came from
+  source.push_back(root2);
+  for (size_t w = 0; w < wide.size(); ++w) {
+    int const node2 = source[w];
     int kids[4];
     int nk = 0;
-    if (b.nodes[w.node2].leaf()) {
-      kids[nk++] = w.node2;
+    if (b.nodes[size_t(node2)].leaf()) {
+      kids[nk++] = node2;
     } else {
-      kids[nk++] = b.nodes[w.node2].left;
-      kids[nk++] = b.nodes[w.node2].right;
+      kids[nk++] = b.nodes[size_t(node2)].left;
+      kids[nk++] = b.nodes[size_t(node2)].right;
       while (nk < 4) {
         int pick = -1;
         float bestA = -1.f;
         for (int k = 0; k < nk; ++k)
-          if (!b.nodes[kids[k]].leaf() && b.nodes[kids[k]].box.area() > bestA) bestA = b.nodes[kids[k]].box.area(), pick = k;
+          if (!b.nodes[size_t(kids[k])].leaf() && b.nodes[size_t(kids[k])].box.area() > bestA) bestA = b.nodes[size_t(kids[k])].box.area(), pick = k;
         if (pick < 0) break;
         int const open = kids[pick];
-        kids[pick] = b.nodes[open].left;
-        kids[nk++] = b.nodes[open].right;
+        kids[pick] = b.nodes[size_t(open)].left;
+        kids[nk++] = b.nodes[size_t(open)].right;
       }
     }
+    Wide W = wide[w];
+    W.nk = nk;
+    W.nInner = 0;
+    for (int k = 0; k < nk; ++k)
+      if (!b.nodes[size_t(kids[k])].leaf()) W.kids[W.nInner++] = kids[k];
+    int at = W.nInner;
+    for (int k = 0; k < nk; ++k)
+      if (b.nodes[size_t(kids[k])].leaf()) W.kids[at++] = kids[k];
+    wide[w] = W;
+    out.depth = std::max(out.depth, W.depth);
+    for (int k = 0; k < W.nInner; ++k) {  // consecutive indices: size() .. size() + nInner - 1
+      Wide c;
+      c.depth = W.depth + 1;
+      wide.push_back(c);
+      source.push_back(W.kids[k]);
+    }
+  }
+  // encode in index order; leaves of a node become consecutive pairs
+  out.nodes.resize(wide.size());
+  uint32_t nextChild = 1;
+  for (size_t w = 0; w < wide.size(); ++w) {
+    Wide const& W = wide[w];
+    Box kb[4];
+    for (int k = 0; k < W.nk; ++k) kb[k] = b.nodes[size_t(W.kids[k])].box;
     Bvh4Node nd;
-    for (int k = 0; k < 4; ++k) {
-      nd.pad[k] = 0;
-      if (k >= nk) {
-        nd.minx[k] = nd.miny[k] = nd.minz[k] = std::numeric_limits<float>::infinity();
-        nd.maxx[k] = nd.maxy[k] = nd.maxz[k] = -std::numeric_limits<float>::infinity();
-        nd.child[k] = kBvhEmpty;
-        continue;
-      }
-      Node2 const& c = b.nodes[kids[k]];
-      nd.minx[k] = c.box.lo[0], nd.miny[k] = c.box.lo[1], nd.minz[k] = c.box.lo[2];
-      nd.maxx[k] = c.box.hi[0], nd.maxy[k] = c.box.hi[1], nd.maxz[k] = c.box.hi[2];
-      if (c.leaf()) {
-        nd.child[k] = bvhLeafRef(c.first, c.count);
-      } else {
-        uint32_t const id4 = uint32_t(out.nodes.size());
-        out.nodes.emplace_back();
-        nd.child[k] = id4;
-        stack.push_back({kids[k], id4, w.depth + 1});
-      }
+    encodeNode(nd, kb, W.nk, W.nInner);
+    nd.childBase = nextChild;
+    nextChild += uint32_t(W.nInner);
+    nd.leafBase = uint32_t(out.pairTris.size() / 2);
+    for (int k = W.nInner; k < W.nk; ++k) {
+      Node2 const& c = b.nodes[size_t(W.kids[k])];
+      uint32_t const t0 = b.order[c.first], t1 = b.order[c.first + (c.count > 1 ? 1 : 0)];
+      out.pairTris.push_back(t0), out.pairTris.push_back(t1);
     }
-    out.nodes[w.node4] = nd;
+    out.nodes[w] = nd;
   }
   return out;
 }

@@ -1,12 +1,15 @@
-// bvh_device.hpp -- per-lane traversal of the 4-wide BVH (bvh.hpp) on gfx950.
+// bvh_device.hpp -- per-lane traversal of the 4-wide quantised BVH (bvh.hpp) on gfx950.
 //
-// One lane = one ray.  The traversal stack lives in LDS as [entry][thread] (16 entries, conflict
-// free: consecutive lanes hit consecutive banks); deeper entries -- rare -- go to a per-lane column of
-// a global overflow array.  A node is seven 16-byte per-lane loads (boxes as SoA + child refs), the
-// four slab tests are plain VALU min/max, hit children are ordered by a 5-exchange network and the
-// nearest is entered directly (no push/pop).  Leaves hold <= 2 triangles (one pair), in traversal
-// order, tested with the SAME Moeller-Trumbore core as the brute-force loop, so the closest hit
-// (t,u,v and triangle, lowest original index on ties) is bit-identical to brute force.
+// One lane = one ray.  What bounds this on gfx950 is the CU's vector-memory front end (tools/ubench/gather.hip,
+// bvh.hpp header): a traversal step costs ~0.7 clocks of the L1 path per 16-byte per-lane load and ~2.5 per 64-byte
+// sector touched, at any occupancy.  So a node is ONE sector read with THREE loads (quantised child boxes, implicit
+// child references) and a leaf is one 80-byte triangle pair (five loads).  The traversal stack lives in LDS as
+// [entry][thread] (16 entries, conflict free: consecutive lanes hit consecutive banks); deeper entries -- rare -- go to
+// a per-lane column of a global overflow array.  The four slab tests work on the quantised planes directly
+// (t = q * (scale * inv) + (origin - o) * inv: one v_cvt_f32_ubyteN + one FMA per plane), hit children are ordered by
+// a 5-exchange network and the nearest is entered directly (no push/pop).  Leaves are tested with the SAME
+// Moeller-Trumbore core as the brute-force loop, so the closest hit (t,u,v and triangle, lowest original index on ties)
+// is bit-identical to brute force.
 #pragma once
 
 #include "bvh.hpp"
@@ -49,25 +52,6 @@ struct BvhStack {
   }
 };
 
-struct SlabRay {
-  f3 o, inv;
-};
-DMT_DEV SlabRay slab_ray(f3 o, f3 d) {
-  SlabRay r;
-  r.o = o;
-  r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // +-inf for zero components: handled by min/max
-  return r;
-}
-// entry distance of the box (+inf on a miss); conservative: boxes are padded by the builder and the
-// exit distance is widened by 2 ulp-ish (pbrt's 1 + 2*gamma(3))
-DMT_DEV float slab(SlabRay const& r, float lx, float ly, float lz, float hx, float hy, float hz, float tmax) {
-  float const ax = (lx - r.o.x) * r.inv.x, bx = (hx - r.o.x) * r.inv.x;
-  float const ay = (ly - r.o.y) * r.inv.y, by = (hy - r.o.y) * r.inv.y;
-  float const az = (lz - r.o.z) * r.inv.z, bz = (hz - r.o.z) * r.inv.z;
-  float const tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
-  float const tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax)) * 1.0000004f;
-  return tn <= tf ? tn : kInf;
-}
 DMT_DEV void cswap(float& ka, uint32_t& ra, float& kb, uint32_t& rb) {
   bool const sw = kb < ka;
   float const k = sw ? kb : ka;
@@ -81,13 +65,14 @@ struct PairHit {
   v2f t, u, v;
   uint32_t orig0, orig1;
 };
-DMT_DEV PairHit pair_test(TriPair const& P, f3 o, f3 d) {
+DMT_DEV PairHit pair_test(TriPair const* P, f3 o, f3 d) {
   // five 16-byte loads; consecutive floats of the record are (first, second) pairs
-  float4 const a = *reinterpret_cast<float4 const*>(&P.p0x[0]);  // p0x p0x p0y p0y
-  float4 const b = *reinterpret_cast<float4 const*>(&P.p0z[0]);  // p0z p0z e0x e0x
-  float4 const c = *reinterpret_cast<float4 const*>(&P.e0y[0]);  // e0y e0y e0z e0z
-  float4 const e = *reinterpret_cast<float4 const*>(&P.e1x[0]);  // e1x e1x e1y e1y
-  float4 const f = *reinterpret_cast<float4 const*>(&P.e1z[0]);  // e1z e1z orig orig
+  float4 const* const q = reinterpret_cast<float4 const*>(P);
+  float4 const a = q[0];  // p0x p0x p0y p0y
+  float4 const b = q[1];  // p0z p0z e0x e0x
+  float4 const c = q[2];  // e0y e0y e0z e0z
+  float4 const e = q[3];  // e1x e1x e1y e1y
+  float4 const f = q[4];  // e1z e1z orig orig
   PairHit h;
   v2f det;
   mt_core9_tri2(v2f{a.x, a.y}, v2f{a.z, a.w}, v2f{b.x, b.y}, v2f{b.z, b.w}, v2f{c.x, c.y}, v2f{c.z, c.w}, v2f{e.x, e.y},
@@ -104,120 +89,28 @@ struct TraversalCounters {  // per-lane work counters (stats build of the kernel
   uint32_t overflowPushes = 0;  // stack pushes that went to the global overflow area (entries >= kBvhLdsStack)
 };
 
-// closest hit: bestTri = ORIGINAL triangle index or -1
-template <bool STATS = false>
-DMT_DEV void bvh_closest(BvhView const& bv, bool active, f3 o, f3 d, uint32_t gtid, int& bestTri, float& bt,
-                         float& bu, float& bvv, TraversalCounters* tc = nullptr) {
-  bt = kInf, bestTri = -1, bu = 0.f, bvv = 0.f;
-  uint32_t bestOrig = 0xFFFFFFFFu;
-  SlabRay const sr = slab_ray(o, d);
-  BvhStack st{0, bv.overflow + gtid, bv.overflowStride};
-  uint32_t cur = active ? 0u : kBvhEmpty;  // node 0 = root
-  while (cur != kBvhEmpty) {
-    if (!(cur & kBvhLeafFlag)) {
-      Bvh4Node const& n = bv.nodes[cur];
-      if constexpr (STATS) ++tc->nodes;
-      float k0 = slab(sr, n.minx[0], n.miny[0], n.minz[0], n.maxx[0], n.maxy[0], n.maxz[0], bt);
-      float k1 = slab(sr, n.minx[1], n.miny[1], n.minz[1], n.maxx[1], n.maxy[1], n.maxz[1], bt);
-      float k2 = slab(sr, n.minx[2], n.miny[2], n.minz[2], n.maxx[2], n.maxy[2], n.maxz[2], bt);
-      float k3 = slab(sr, n.minx[3], n.miny[3], n.minz[3], n.maxx[3], n.maxy[3], n.maxz[3], bt);
-      uint32_t r0 = n.child[0], r1 = n.child[1], r2 = n.child[2], r3 = n.child[3];
-      // an empty slot's (+inf,-inf) box is NOT a miss for the slab test (min/max swap it): mask by ref
-      k0 = r0 == kBvhEmpty ? kInf : k0, k1 = r1 == kBvhEmpty ? kInf : k1;
-      k2 = r2 == kBvhEmpty ? kInf : k2, k3 = r3 == kBvhEmpty ? kInf : k3;
-      cswap(k0, r0, k1, r1);
-      cswap(k2, r2, k3, r3);
-      cswap(k0, r0, k2, r2);
-      cswap(k1, r1, k3, r3);
-      cswap(k1, r1, k2, r2);
-      if (k3 < kInf) st.push(r3);  // far to near, nearest entered directly
-      if (k2 < kInf) st.push(r2);
-      if (k1 < kInf) st.push(r1);
-      cur = k0 < kInf ? r0 : st.pop();
-    } else {
-      uint32_t const first = cur & 0x0FFFFFFFu;
-      uint32_t const cnt = ((cur >> 28) & 7u) + 1u;
-      for (uint32_t j = 0; j < cnt; ++j) {
-        PairHit const h = pair_test(bv.pairs[first + j], o, d);
-        if constexpr (STATS) tc->tris += h.orig0 != h.orig1 ? 2u : 1u;  // an odd leaf repeats its last triangle
-        // brute force keeps the lowest index among equal t (strict < in index order)
-        if (h.valid0 && (h.t.x < bt || (h.t.x == bt && h.orig0 < bestOrig)))
-          bt = h.t.x, bu = h.u.x, bvv = h.v.x, bestOrig = h.orig0, bestTri = int(h.orig0);
-        if (h.valid1 && (h.t.y < bt || (h.t.y == bt && h.orig1 < bestOrig)))
-          bt = h.t.y, bu = h.u.y, bvv = h.v.y, bestOrig = h.orig1, bestTri = int(h.orig1);
-      }
-      cur = st.pop();
-    }
-  }
-}
-
-// any hit with t < tmax
-template <bool STATS = false>
-DMT_DEV bool bvh_any(BvhView const& bv, bool active, f3 o, f3 d, float tmax, uint32_t gtid,
-                     TraversalCounters* tc = nullptr) {
-  SlabRay const sr = slab_ray(o, d);
-  BvhStack st{0, bv.overflow + gtid, bv.overflowStride};
-  uint32_t cur = active ? 0u : kBvhEmpty;
-  bool occluded = false;
-  while (cur != kBvhEmpty) {
-    if (!(cur & kBvhLeafFlag)) {
-      Bvh4Node const& n = bv.nodes[cur];
-      if constexpr (STATS) ++tc->nodes;
-      float const k0 = slab(sr, n.minx[0], n.miny[0], n.minz[0], n.maxx[0], n.maxy[0], n.maxz[0], tmax);
-      float const k1 = slab(sr, n.minx[1], n.miny[1], n.minz[1], n.maxx[1], n.maxy[1], n.maxz[1], tmax);
-      float const k2 = slab(sr, n.minx[2], n.miny[2], n.minz[2], n.maxx[2], n.maxy[2], n.maxz[2], tmax);
-      float const k3 = slab(sr, n.minx[3], n.miny[3], n.minz[3], n.maxx[3], n.maxy[3], n.maxz[3], tmax);
-      uint32_t const r0 = n.child[0], r1 = n.child[1], r2 = n.child[2], r3 = n.child[3];
-      uint32_t next = kBvhEmpty;  // empty slots are masked by ref (their box is not a slab miss)
-      if (k3 < kInf && r3 != kBvhEmpty) next = r3;
-      if (k2 < kInf && r2 != kBvhEmpty) {
-        if (next != kBvhEmpty) st.push(next);
-        next = r2;
-      }
-      if (k1 < kInf && r1 != kBvhEmpty) {
-        if (next != kBvhEmpty) st.push(next);
-        next = r1;
-      }
-      if (k0 < kInf && r0 != kBvhEmpty) {
-        if (next != kBvhEmpty) st.push(next);
-        next = r0;
-      }
-      cur = next != kBvhEmpty ? next : st.pop();
-    } else {
-      uint32_t const first = cur & 0x0FFFFFFFu;
-      uint32_t const cnt = ((cur >> 28) & 7u) + 1u;
-      for (uint32_t j = 0; j < cnt; ++j) {
-        PairHit const h = pair_test(bv.pairs[first + j], o, d);
-        if constexpr (STATS) tc->tris += h.orig0 != h.orig1 ? 2u : 1u;  // an odd leaf repeats its last triangle
-        if ((h.valid0 && h.t.x < tmax) || (h.valid1 && h.t.y < tmax)) occluded = true;
-      }
-      cur = occluded ? kBvhEmpty : st.pop();
-    }
-  }
-  return occluded;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Resumable traversal: one step (one node, or one leaf) per call, so that the lanes of a wave can be at
 // different points of different traversals and nobody waits for the wave's longest ray.  A lane first
 // runs its closest-hit traversal, then (same stack) the any-hit traversal of its pending shadow ray.
 // Both phases share one code path (children are always distance-sorted) to keep divergence low.
 // ---------------------------------------------------------------------------------------------
-// Slab setup of the resumable traversal: t = plane * inv + oi (one FMA per plane) with the near / far plane of
-// each axis picked by the sign of the direction, so that a child costs 6 FMA + max3 + min3 instead of
-// 12 sub/mul + 6 min/max.  Both shortcuts only have to stay CONSERVATIVE: the FMA form errs by
-// ~eps * (|plane| + |o|) * |inv|, i.e. ~1e-7 of the coordinates in space, 30x below the builder's box padding
-// (4e-6 * |coordinate| + 1e-5 * extent); a zero direction component gives inf - inf = NaN on that axis, which
-// max/min drop, i.e. the axis is ignored.  Hits are decided by the triangle test alone.
+// Slab setup: a child's plane at quantised coordinate q is at  origin + q * scale, so its ray parameter is
+//   t = (origin + q * scale - o) * inv = q * (scale * inv) + (origin * inv + oi),   oi = -o * inv,
+// i.e. one FMA per plane after three multiplies and three FMAs per node.  The near / far plane of each axis is picked
+// by the sign of the direction.  Everything here only has to stay CONSERVATIVE: the evaluation errs by a few ulp of
+// |origin - o| * |inv|, i.e. ~3e-7 of the coordinates in space, more than ten times below the builder's box padding
+// (4e-6 * |coordinate| + 1e-5 * extent); a zero direction component gives inf * 0 or inf - inf = NaN on that axis,
+// which max/min drop, i.e. the axis is ignored.  Hits are decided by the triangle test alone.
 struct SlabRay2 {
   f3 inv, oi;
-  uint32_t nearOff;  // byte offsets of the near planes inside a node, packed: x | y << 8 | z << 16
+  bool negx, negy, negz;
 };
 DMT_DEV SlabRay2 slab_ray2(f3 o, f3 d) {
   SlabRay2 r;
   r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   r.oi = mk3(-o.x * r.inv.x, -o.y * r.inv.y, -o.z * r.inv.z);
-  r.nearOff = (d.x < 0.f ? 48u : 0u) | ((d.y < 0.f ? 64u : 16u) << 8) | ((d.z < 0.f ? 80u : 32u) << 16);
+  r.negx = d.x < 0.f, r.negy = d.y < 0.f, r.negz = d.z < 0.f;
   return r;
 }
 enum : int { TR_IDLE = 0, TR_CLOSEST = 1, TR_SHADOW = 2, TR_DONE = 3 };
@@ -225,6 +118,7 @@ struct Traversal {
   int phase;
   bool doC, doS;     // what this round of the lane consists of
   uint32_t cur;
+  uint32_t pend;     // postponed leaf (megakernel_body_bvh): found, not yet tested; kBvhEmpty = none
   BvhStack stack;
   f3 o, d;           // ray of the current phase
   SlabRay2 sr;
@@ -238,33 +132,52 @@ DMT_DEV void trav_set_ray(Traversal& tv, f3 o, f3 d) {
   tv.o = o, tv.d = d;
   tv.sr = slab_ray2(o, d);
   tv.cur = 0u;
+  tv.pend = kBvhEmpty;
   tv.stack.sp = 0;
 }
-// entry distance of one child (+inf on a miss) from its near / far plane triples
-DMT_DEV float slab2(float nx, float ny, float nz, float fx, float fy, float fz, SlabRay2 const& r, float tlimit,
-                    uint32_t ref) {
-  float const tn = fmaxf(fmaxf(fmaxf(fma_(nx, r.inv.x, r.oi.x), fma_(ny, r.inv.y, r.oi.y)), fma_(nz, r.inv.z, r.oi.z)), 0.f);
+template <int K>
+DMT_DEV float qbyte(uint32_t w) {  // byte K of w as a float: v_cvt_f32_ubyteK
+  return float((w >> (8 * K)) & 0xFFu);
+}
+// entry distance of child K (+inf on a miss or an empty slot)
+template <int K>
+DMT_DEV float slab_q(uint32_t nqx, uint32_t nqy, uint32_t nqz, uint32_t fqx, uint32_t fqy, uint32_t fqz, f3 a, f3 b, float tlimit,
+                     uint32_t count) {
+  float const tn = fmaxf(fmaxf(fmaxf(fma_(qbyte<K>(nqx), a.x, b.x), fma_(qbyte<K>(nqy), a.y, b.y)), fma_(qbyte<K>(nqz), a.z, b.z)), 0.f);
   float const tf =
-      fminf(fminf(fminf(fma_(fx, r.inv.x, r.oi.x), fma_(fy, r.inv.y, r.oi.y)), fma_(fz, r.inv.z, r.oi.z)), tlimit) * 1.0000004f;
-  // an empty slot's (+inf,-inf) box is not reliably a miss (NaNs are dropped): mask by ref
-  return (tn <= tf && ref != kBvhEmpty) ? tn : kInf;
+      fminf(fminf(fminf(fma_(qbyte<K>(fqx), a.x, b.x), fma_(qbyte<K>(fqy), a.y, b.y)), fma_(qbyte<K>(fqz), a.z, b.z)), tlimit) * 1.0000004f;
+  // an empty slot's inverted box is not reliably a miss (NaNs are dropped): mask by the child count
+  return (tn <= tf && uint32_t(K) < count) ? tn : kInf;
 }
 // node step: cur is an inner node
 template <bool STATS = false>
 DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
   float const tlimit = tv.phase == TR_CLOSEST ? tv.bt : tv.tmax;
-  char const* const nb = reinterpret_cast<char const*>(bv.nodes + tv.cur);
+  uint4 const* const nb = reinterpret_cast<uint4 const*>(bv.nodes + tv.cur);
   if constexpr (STATS) ++tc->nodes;
-  uint32_t const ox = tv.sr.nearOff & 0xFFu, oy = (tv.sr.nearOff >> 8) & 0xFFu, oz = (tv.sr.nearOff >> 16) & 0xFFu;
-  float4 const nx = *reinterpret_cast<float4 const*>(nb + ox), fx = *reinterpret_cast<float4 const*>(nb + (48u - ox));
-  float4 const ny = *reinterpret_cast<float4 const*>(nb + oy), fy = *reinterpret_cast<float4 const*>(nb + (80u - oy));
-  float4 const nz = *reinterpret_cast<float4 const*>(nb + oz), fz = *reinterpret_cast<float4 const*>(nb + (112u - oz));
-  uint4 const ch = *reinterpret_cast<uint4 const*>(nb + 96);
-  uint32_t r0 = ch.x, r1 = ch.y, r2 = ch.z, r3 = ch.w;
-  float k0 = slab2(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, tv.sr, tlimit, r0);
-  float k1 = slab2(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, tv.sr, tlimit, r1);
-  float k2 = slab2(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, tv.sr, tlimit, r2);
-  float k3 = slab2(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, tv.sr, tlimit, r3);
+  uint4 const w0 = nb[0];  // ox oy oz meta
+  uint4 const w1 = nb[1];  // childBase leafBase qlox qhix
+  uint4 const w2 = nb[2];  // qloy qhiy qloz qhiz
+  uint32_t const meta = w0.w;
+  f3 const scale = mk3(__uint_as_float((meta << 23) & 0x7F800000u), __uint_as_float((meta << 15) & 0x7F800000u),
+                       __uint_as_float((meta << 7) & 0x7F800000u));
+  f3 const a = mk3(scale.x * tv.sr.inv.x, scale.y * tv.sr.inv.y, scale.z * tv.sr.inv.z);
+  f3 const b = mk3(fma_(__uint_as_float(w0.x), tv.sr.inv.x, tv.sr.oi.x), fma_(__uint_as_float(w0.y), tv.sr.inv.y, tv.sr.oi.y),
+                   fma_(__uint_as_float(w0.z), tv.sr.inv.z, tv.sr.oi.z));
+  uint32_t const nqx = tv.sr.negx ? w1.w : w1.z, fqx = tv.sr.negx ? w1.z : w1.w;
+  uint32_t const nqy = tv.sr.negy ? w2.y : w2.x, fqy = tv.sr.negy ? w2.x : w2.y;
+  uint32_t const nqz = tv.sr.negz ? w2.w : w2.z, fqz = tv.sr.negz ? w2.z : w2.w;
+  uint32_t const inner = (meta >> 24) & 0xFu, count = meta >> 28;
+  float k0 = slab_q<0>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, count);
+  float k1 = slab_q<1>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, count);
+  float k2 = slab_q<2>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, count);
+  float k3 = slab_q<3>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, count);
+  // implicit references: child k < inner is node childBase + k, else leaf leafBase + (k - inner)
+  uint32_t const lb = w1.y - inner;  // wraps when leafBase < inner; lb + k is exact again for every k >= inner
+  uint32_t r0 = 0u < inner ? w1.x : (lb | kBvhLeafFlag);
+  uint32_t r1 = 1u < inner ? w1.x + 1u : ((lb + 1u) | kBvhLeafFlag);
+  uint32_t r2 = 2u < inner ? w1.x + 2u : ((lb + 2u) | kBvhLeafFlag);
+  uint32_t r3 = 3u < inner ? w1.x + 3u : ((lb + 3u) | kBvhLeafFlag);
   cswap(k0, r0, k1, r1);
   cswap(k2, r2, k3, r3);
   cswap(k0, r0, k2, r2);
@@ -291,25 +204,83 @@ DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc =
     tv.cur = p0 ? r0 : tv.stack.pop();
   }
 }
-// leaf step: cur is a leaf reference (1-2 triangle pairs)
+// leaf test: `ref` is a leaf reference (one triangle pair); updates the best hit / the occlusion flag only
+template <bool STATS = false>
+DMT_DEV void trav_leaf_ref(BvhView const& bv, Traversal& tv, uint32_t ref, TraversalCounters* tc = nullptr) {
+  PairHit const h = pair_test(bv.pairs + (ref & ~kBvhLeafFlag), tv.o, tv.d);
+  if constexpr (STATS) tc->tris += h.orig0 != h.orig1 ? 2u : 1u;  // a one-triangle leaf repeats its triangle
+  if (tv.phase == TR_CLOSEST) {  // brute force keeps the lowest index among equal t (strict < in index order)
+    if (h.valid0 && (h.t.x < tv.bt || (h.t.x == tv.bt && h.orig0 < tv.bestOrig)))
+      tv.bt = h.t.x, tv.bu = h.u.x, tv.bv = h.v.x, tv.bestOrig = h.orig0, tv.bestTri = int(h.orig0);
+    if (h.valid1 && (h.t.y < tv.bt || (h.t.y == tv.bt && h.orig1 < tv.bestOrig)))
+      tv.bt = h.t.y, tv.bu = h.u.y, tv.bv = h.v.y, tv.bestOrig = h.orig1, tv.bestTri = int(h.orig1);
+  } else if ((h.valid0 && h.t.x < tv.tmax) || (h.valid1 && h.t.y < tv.tmax)) {
+    tv.occluded = true;
+  }
+}
+// leaf step of the synchronous traversal: cur is a leaf reference
 template <bool STATS = false>
 DMT_DEV void trav_leaf(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
-  bool const closest = tv.phase == TR_CLOSEST;
-  uint32_t const first = tv.cur & 0x0FFFFFFFu;
-  uint32_t const cnt = kBvhMaxLeafTris <= 2 ? 1u : ((tv.cur >> 28) & 7u) + 1u;  // builder's leaf size: one pair
-  for (uint32_t j = 0; j < cnt; ++j) {
-    PairHit const h = pair_test(bv.pairs[first + j], tv.o, tv.d);
-    if constexpr (STATS) tc->tris += h.orig0 != h.orig1 ? 2u : 1u;  // an odd leaf repeats its last triangle
-    if (closest) {
-      if (h.valid0 && (h.t.x < tv.bt || (h.t.x == tv.bt && h.orig0 < tv.bestOrig)))
-        tv.bt = h.t.x, tv.bu = h.u.x, tv.bv = h.v.x, tv.bestOrig = h.orig0, tv.bestTri = int(h.orig0);
-      if (h.valid1 && (h.t.y < tv.bt || (h.t.y == tv.bt && h.orig1 < tv.bestOrig)))
-        tv.bt = h.t.y, tv.bu = h.u.y, tv.bv = h.v.y, tv.bestOrig = h.orig1, tv.bestTri = int(h.orig1);
-    } else if ((h.valid0 && h.t.x < tv.tmax) || (h.valid1 && h.t.y < tv.tmax)) {
-      tv.occluded = true;
-    }
+  trav_leaf_ref<STATS>(bv, tv, tv.cur, tc);
+  tv.cur = (tv.phase != TR_CLOSEST && tv.occluded) ? kBvhEmpty : tv.stack.pop();
+}
+// Postponed leaves (megakernel_body_bvh; "speculative traversal", Aila & Laine 2009): a lane that reaches a leaf parks
+// it in `pend` and goes on with the next stack entry, so it keeps taking part in the wave's NODE steps; the wave runs a
+// LEAF step when enough lanes are blocked (a second leaf found, or nothing else left).  The order in which a ray's
+// nodes and leaves are processed changes, the set of candidates and the comparison rule do not: the closest hit and the
+// any-hit answer are the same (a node visited before its pending leaf was tested is merely culled less tightly).
+DMT_DEV void trav_park_leaf(Traversal& tv) {  // call when cur may be a leaf: park it if the slot is free
+  if (tv.cur != kBvhEmpty && (tv.cur & kBvhLeafFlag) != 0u && tv.pend == kBvhEmpty) {
+    tv.pend = tv.cur;
+    tv.cur = tv.stack.pop();
   }
-  tv.cur = (!closest && tv.occluded) ? kBvhEmpty : tv.stack.pop();
+}
+template <bool STATS = false>
+DMT_DEV void trav_leaf_pending(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
+  trav_leaf_ref<STATS>(bv, tv, tv.pend, tc);
+  tv.pend = kBvhEmpty;
+  if (tv.phase != TR_CLOSEST && tv.occluded) tv.cur = kBvhEmpty, tv.stack.sp = 0;  // any-hit: done
+  trav_park_leaf(tv);
+}
+
+// ---- whole traversals of one ray per lane (test kernels, lane_step<BVH>): the same step functions in a loop ----
+template <bool STATS>
+DMT_DEV void trav_run(BvhView const& bv, Traversal& tv, TraversalCounters* tc) {
+  for (;;) {
+    bool const live = tv.cur != kBvhEmpty;
+    if (!__any(live)) break;
+    bool const onLeaf = live && (tv.cur & kBvhLeafFlag) != 0u;
+    if (live && !onLeaf) trav_node<STATS>(bv, tv, tc);
+    if (onLeaf) trav_leaf<STATS>(bv, tv, tc);
+  }
+}
+// closest hit: bestTri = ORIGINAL triangle index or -1
+template <bool STATS = false>
+DMT_DEV void bvh_closest(BvhView const& bv, bool active, f3 o, f3 d, uint32_t gtid, int& bestTri, float& bt,
+                         float& bu, float& bvv, TraversalCounters* tc = nullptr) {
+  Traversal tv{};
+  tv.stack.ovf = bv.overflow + gtid, tv.stack.stride = bv.overflowStride;
+  if constexpr (STATS) tv.stack.ovfCount = &tc->overflowPushes;
+  tv.phase = TR_CLOSEST;
+  tv.bt = kInf, tv.bestTri = -1, tv.bestOrig = 0xFFFFFFFFu, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false, tv.tmax = kInf;
+  trav_set_ray(tv, o, d);
+  if (!active) tv.cur = kBvhEmpty;
+  trav_run<STATS>(bv, tv, tc);
+  bestTri = tv.bestTri, bt = tv.bt, bu = tv.bu, bvv = tv.bv;
+}
+// any hit with t < tmax
+template <bool STATS = false>
+DMT_DEV bool bvh_any(BvhView const& bv, bool active, f3 o, f3 d, float tmax, uint32_t gtid,
+                     TraversalCounters* tc = nullptr) {
+  Traversal tv{};
+  tv.stack.ovf = bv.overflow + gtid, tv.stack.stride = bv.overflowStride;
+  if constexpr (STATS) tv.stack.ovfCount = &tc->overflowPushes;
+  tv.phase = TR_SHADOW;
+  tv.bt = kInf, tv.bestTri = -1, tv.bestOrig = 0xFFFFFFFFu, tv.occluded = false, tv.tmax = tmax;
+  trav_set_ray(tv, o, d);
+  if (!active) tv.cur = kBvhEmpty;
+  trav_run<STATS>(bv, tv, tc);
+  return tv.occluded;
 }
 
 }  // namespace dmt

@@ -868,9 +868,16 @@ DMT_DEV void megakernel_body() {
 // shading runs for all waiting lanes at once when at least DMT_BVH_SHADE_THRESHOLD of them are waiting (or
 // nobody is traversing).  Incoherent rays take very different numbers of steps; with a pass-synchronous
 // loop the wave ran at 14 % lane utilisation.
+#ifndef DMT_BVH_DUMMY_LDS
+#define DMT_BVH_DUMMY_LDS 0  // occupancy experiments: extra LDS bytes per block (fewer resident blocks per CU)
+#endif
 template <bool STATS = false, bool ENV = false, bool AREA = false>
 DMT_DEV void megakernel_body_bvh() {
   KArgs const Pk = kargs_base();
+#if DMT_BVH_DUMMY_LDS > 0
+  __shared__ volatile char s_dummy[DMT_BVH_DUMMY_LDS];
+  if (threadIdx.x == 0) s_dummy[blockIdx.x % DMT_BVH_DUMMY_LDS] = 1;
+#endif
   LaneStats ls;
   int const lane = int(threadIdx.x) & 63;
   uint32_t const gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -948,6 +955,8 @@ DMT_DEV void megakernel_body_bvh() {
         int const nNode = __popcll(__ballot(onNode)), nLeaf = __popcll(__ballot(onLeaf));
         if (nNode + nLeaf == 0) break;
         if (__popcll(__ballot(tv.phase == TR_DONE)) >= DMT_BVH_SHADE_THRESHOLD) break;
+        // (parking a found leaf and carrying on with node steps -- bvh_device.hpp trav_park_leaf -- was measured here:
+        //  8 % fewer wave iterations but 5 % slower, the extra dependent LDS pop lengthens every node step)
         if (nNode * DMT_BVH_NODE_WEIGHT >= nLeaf * DMT_BVH_LEAF_WEIGHT) {
           if constexpr (STATS) ++ls.itNode;
           if (onNode) trav_node<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
@@ -1232,7 +1241,7 @@ struct dmt_ctx {
   size_t overflowThreads = 0;
   bool haveBvh = false;
   int bvhDepth = 0;
-  uint32_t bvhNodeCount = 0;
+  uint32_t bvhNodeCount = 0, bvhPairCount = 0;
   int blocksPerCUBvh = 0;
   int blocksPerCUEnv = 0, blocksPerCUBvhEnv = 0;
   float* d_env = nullptr;  // A18: one allocation holding the five tables and the image
@@ -1406,40 +1415,27 @@ int ensureOverflow(dmt_ctx* ctx, size_t threads) {
   return DMT_OK;
 }
 
-// (re)build the 4-wide BVH of the uploaded soup and upload nodes + slot-ordered triangle records
+// (re)build the 4-wide BVH of the uploaded soup and upload nodes + triangle pairs
 int buildBvh(dmt_ctx* ctx) {
   uint32_t const n = ctx->triCount;
   bvh_build::Result r = bvh_build::build(ctx->h_xs.data(), ctx->h_ys.data(), ctx->h_zs.data(), n);
-  // leaf storage: triangle pairs (bvh.hpp TriPair); leaf references are rewritten from (first slot, triangles)
-  // to (first pair, pairs).  Edges are the reference's own subtractions (CC/private/shapes.cu:10-11) in IEEE fp32.
-  std::vector<TriPair> pairs;
-  pairs.reserve(size_t(n) / 2 + r.nodes.size());
-  auto put = [&](TriPair& P, int half, uint32_t slot) {
-    uint32_t const i = r.slotToTri[slot];
-    float const* xs = &ctx->h_xs[4 * size_t(i)];
-    float const* ys = &ctx->h_ys[4 * size_t(i)];
-    float const* zs = &ctx->h_zs[4 * size_t(i)];
-    P.p0x[half] = xs[0], P.p0y[half] = ys[0], P.p0z[half] = zs[0];
-    P.e0x[half] = xs[1] - xs[0], P.e0y[half] = ys[1] - ys[0], P.e0z[half] = zs[1] - zs[0];
-    P.e1x[half] = xs[2] - xs[0], P.e1y[half] = ys[2] - ys[0], P.e1z[half] = zs[2] - zs[0];
-    P.orig[half] = i;
-  };
-  for (Bvh4Node& nd : r.nodes) {
-    for (int k = 0; k < 4; ++k) {
-      uint32_t const ref = nd.child[k];
-      if (ref == kBvhEmpty || !(ref & kBvhLeafFlag)) continue;
-      uint32_t const first = ref & 0x0FFFFFFFu, cnt = ((ref >> 28) & 7u) + 1u;
-      uint32_t const firstPair = uint32_t(pairs.size());
-      for (uint32_t j = 0; j < cnt; j += 2) {
-        TriPair P{};
-        put(P, 0, first + j);
-        put(P, 1, first + (j + 1 < cnt ? j + 1 : j));
-        pairs.push_back(P);
-      }
-      if (pairs.size() > 0x0FFFFFFFull) return fail(ctx, DMT_ERR_INVALID, "BVH: too many triangle pairs");
-      nd.child[k] = bvhLeafRef(firstPair, uint32_t(pairs.size()) - firstPair);
+  // leaf storage: triangle pairs (bvh.hpp TriPair).  Edges are the reference's own subtractions
+  // (CC/private/shapes.cu:10-11) in IEEE fp32.
+  size_t const npairs = r.pairTris.size() / 2;
+  if (npairs > 0x7FFFFFFFull || r.nodes.size() > 0x7FFFFFFFull) return fail(ctx, DMT_ERR_INVALID, "BVH: too many nodes / triangle pairs");
+  std::vector<TriPair> pairs(npairs);
+  for (size_t p = 0; p < npairs; ++p)
+    for (int half = 0; half < 2; ++half) {
+      uint32_t const i = r.pairTris[2 * p + size_t(half)];
+      float const* xs = &ctx->h_xs[4 * size_t(i)];
+      float const* ys = &ctx->h_ys[4 * size_t(i)];
+      float const* zs = &ctx->h_zs[4 * size_t(i)];
+      TriPair& P = pairs[p];
+      P.p0x[half] = xs[0], P.p0y[half] = ys[0], P.p0z[half] = zs[0];
+      P.e0x[half] = xs[1] - xs[0], P.e0y[half] = ys[1] - ys[0], P.e0z[half] = zs[1] - zs[0];
+      P.e1x[half] = xs[2] - xs[0], P.e1y[half] = ys[2] - ys[0], P.e1z[half] = zs[2] - zs[0];
+      P.orig[half] = i;
     }
-  }
   int rc = devAlloc(ctx, &ctx->d_bvhNodes, r.nodes.size());
   if (rc) return rc;
   rc = devAlloc(ctx, &ctx->d_trisBvh, pairs.size());
@@ -1449,6 +1445,7 @@ int buildBvh(dmt_ctx* ctx) {
     HIP_TRY(ctx, hipMemcpy(ctx->d_trisBvh, pairs.data(), pairs.size() * sizeof(TriPair), hipMemcpyHostToDevice));
   ctx->bvhDepth = r.depth;
   ctx->bvhNodeCount = uint32_t(r.nodes.size());
+  ctx->bvhPairCount = uint32_t(pairs.size());
   ctx->haveBvh = true;
   return DMT_OK;
 }
@@ -1909,8 +1906,9 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   return DMT_OK;
 }
 
-// Host-only: build the BVH of a soup and check its invariants (every triangle in exactly one leaf,
-// every child box encloses all vertices below it, depth within the traversal-stack bound).
+// Host-only: build the BVH of a soup and check its invariants (every triangle in exactly one leaf, every DECODED
+// (quantised) child box encloses all vertices below it and lies inside its parent's decoded box up to one quantisation
+// step, inner children first with consecutive indices, depth within the traversal-stack bound).
 int dmt_bvh_validate(const float* xs, const float* ys, const float* zs, size_t count, int* node_count, int* depth,
                      int* max_leaf) {
   if ((count && (!xs || !ys || !zs)) || count > 0x0FFFFFFFu) return DMT_ERR_INVALID;
@@ -1918,12 +1916,13 @@ int dmt_bvh_validate(const float* xs, const float* ys, const float* zs, size_t c
   if (node_count) *node_count = int(r.nodes.size());
   if (depth) *depth = r.depth;
   std::vector<uint8_t> seen(count, 0);
+  std::vector<uint8_t> nodeSeen(r.nodes.size(), 0);
   int maxLeaf = 0;
-  bool ok = r.depth <= kBvhMaxDepth;
-  // recursive containment check, explicit stack: (node, box of the parent slot)
+  bool ok = r.depth <= kBvhMaxDepth && !r.nodes.empty();
+  size_t const npairs = r.pairTris.size() / 2;
   struct Item {
-    uint32_t ref;
-    float lo[3], hi[3];
+    uint32_t node;
+    float lo[3], hi[3];  // decoded box of the slot this node hangs in
   };
   std::vector<Item> stack;
   float const inf = std::numeric_limits<float>::infinity();
@@ -1931,30 +1930,38 @@ int dmt_bvh_validate(const float* xs, const float* ys, const float* zs, size_t c
   while (!stack.empty() && ok) {
     Item const it = stack.back();
     stack.pop_back();
-    if (it.ref & kBvhLeafFlag) {
-      uint32_t const first = it.ref & 0x0FFFFFFFu, cnt = ((it.ref >> 28) & 7u) + 1u;
-      maxLeaf = std::max(maxLeaf, int(cnt));
-      for (uint32_t s = first; s < first + cnt && ok; ++s) {
-        if (s >= count) { ok = false; break; }
-        uint32_t const t = r.slotToTri[s];
-        if (t >= count || seen[t]++) ok = false;
+    if (it.node >= r.nodes.size() || nodeSeen[it.node]++) { ok = false; break; }
+    Bvh4Node const& n = r.nodes[it.node];
+    int const inner = bvhNodeInner(n), cnt = bvhNodeCount(n);
+    if (inner > cnt || cnt > 4 || (cnt == 0 && count > 0)) { ok = false; break; }
+    for (int k = 0; k < cnt && ok; ++k) {
+      Item c{};
+      bvhChildBox(n, k, c.lo, c.hi);
+      for (int a = 0; a < 3; ++a) {  // nested up to the parent's quantisation step (the child is re-quantised on a finer grid)
+        float const step = bvhNodeScale(n, a);
+        ok = ok && c.lo[a] <= c.hi[a] && c.lo[a] >= it.lo[a] - step && c.hi[a] <= it.hi[a] + step;
+      }
+      if (k < inner) {
+        c.node = n.childBase + uint32_t(k);
+        stack.push_back(c);
+        continue;
+      }
+      size_t const pair = size_t(n.leafBase) + size_t(k - inner);
+      if (pair >= npairs) { ok = false; break; }
+      uint32_t const t0 = r.pairTris[2 * pair], t1 = r.pairTris[2 * pair + 1];
+      maxLeaf = std::max(maxLeaf, t0 == t1 ? 1 : 2);
+      for (int half = 0; half < (t0 == t1 ? 1 : 2) && ok; ++half) {  // a one-triangle leaf repeats its triangle
+        uint32_t const t = half ? t1 : t0;
+        if (t >= count || seen[t]++) { ok = false; break; }
         for (int v = 0; v < 3 && ok; ++v) {
           float const p[3] = {xs[4 * size_t(t) + v], ys[4 * size_t(t) + v], zs[4 * size_t(t) + v]};
-          for (int a = 0; a < 3; ++a) ok = ok && p[a] >= it.lo[a] && p[a] <= it.hi[a];
+          for (int a = 0; a < 3; ++a) ok = ok && p[a] >= c.lo[a] && p[a] <= c.hi[a];
         }
       }
-      continue;
-    }
-    if (it.ref >= r.nodes.size()) { ok = false; break; }
-    Bvh4Node const& n = r.nodes[it.ref];
-    for (int k = 0; k < 4; ++k) {
-      if (n.child[k] == kBvhEmpty) continue;
-      Item c{n.child[k], {n.minx[k], n.miny[k], n.minz[k]}, {n.maxx[k], n.maxy[k], n.maxz[k]}};
-      for (int a = 0; a < 3; ++a) ok = ok && c.lo[a] >= it.lo[a] && c.hi[a] <= it.hi[a];  // nested boxes
-      stack.push_back(c);
     }
   }
   for (size_t i = 0; i < count && ok; ++i) ok = seen[i] == 1;
+  for (size_t i = 0; i < r.nodes.size() && ok; ++i) ok = nodeSeen[i] == 1;
   if (max_leaf) *max_leaf = maxLeaf;
   return ok && maxLeaf <= kBvhMaxLeafTris ? DMT_OK : DMT_ERR_STATE;
 }
