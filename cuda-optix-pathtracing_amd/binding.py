@@ -51,7 +51,7 @@ def load_library():
 # every symbol include/dmt_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTED_SYMBOLS = [
     "dmt_ctx_create", "dmt_ctx_destroy", "dmt_last_error", "dmt_upload_triangles", "dmt_upload_bsdfs",
-    "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_partition", "dmt_set_chunk", "dmt_render_profile",
+    "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_bvh_strategy", "dmt_set_partition", "dmt_set_chunk", "dmt_render_profile",
     "dmt_upload_area_lights", "dmt_upload_envmap", "dmt_clear_envmap", "dmt_envmap_tables", "dmt_test_envmap",
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
     "dmt_render", "dmt_render_stats", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
@@ -206,6 +206,10 @@ class Renderer:
 
     def set_accel(self, mode):
         self._check(self._lib.dmt_set_accel(self._ctx, int(mode)), "dmt_set_accel")
+
+    def set_bvh_strategy(self, strategy, paths_per_pass=0):
+        """0 = automatic, 1 = megakernel, 2 = device-side wavefront (films are bit-identical)."""
+        self._check(self._lib.dmt_set_bvh_strategy(self._ctx, int(strategy), C.c_uint64(int(paths_per_pass))), "dmt_set_bvh_strategy")
 
     def set_partition(self, rank, world):
         self._check(self._lib.dmt_set_partition(self._ctx, int(rank), int(world)), "dmt_set_partition")

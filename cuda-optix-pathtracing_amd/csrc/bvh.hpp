@@ -234,13 +234,13 @@ inline void encodeNode(Bvh4Node& nd, Box const* kid, int nk, int nInner) {
   for (int a = 0; a < 3 && nk > 0; ++a) {
     org[a] = all.lo[a];
     double const ext = double(all.hi[a]) - double(all.lo[a]);
-    int e = -126;
+    int e = -60;  // floor of the scale: the traversal's slope a = scale * (1 / d) must never flush to zero (bvh_device.hpp)
     if (ext > 0.0) {
       int fe;
       (void)std::frexp(ext / 255.0, &fe);  // ext / 255 = m * 2^fe, m in [0.5, 1)  ->  2^fe >= ext / 255
       e = fe;
     }
-    e = std::min(std::max(e, -126), 127);
+    e = std::min(std::max(e, -60), 127);
     while (e < 127 && std::ldexp(255.0, e) < ext) ++e;
     ebytes[a] = uint32_t(e + 127);
     scale[a] = std::ldexp(1.0, e);

@@ -139,15 +139,29 @@ template <int K>
 DMT_DEV float qbyte(uint32_t w) {  // byte K of w as a float: v_cvt_f32_ubyteK
   return float((w >> (8 * K)) & 0xFFu);
 }
-// entry distance of child K (+inf on a miss or an empty slot)
-template <int K>
-DMT_DEV float slab_q(uint32_t nqx, uint32_t nqy, uint32_t nqz, uint32_t fqx, uint32_t fqy, uint32_t fqz, f3 a, f3 b, float tlimit,
-                     uint32_t count) {
-  float const tn = fmaxf(fmaxf(fmaxf(fma_(qbyte<K>(nqx), a.x, b.x), fma_(qbyte<K>(nqy), a.y, b.y)), fma_(qbyte<K>(nqz), a.z, b.z)), 0.f);
-  float const tf =
-      fminf(fminf(fminf(fma_(qbyte<K>(fqx), a.x, b.x), fma_(qbyte<K>(fqy), a.y, b.y)), fma_(qbyte<K>(fqz), a.z, b.z)), tlimit) * 1.0000004f;
-  // an empty slot's inverted box is not reliably a miss (NaNs are dropped): mask by the child count
-  return (tn <= tf && uint32_t(K) < count) ? tn : kInf;
+// Sort key of a child: the entry distance's bit pattern (t >= 0, so unsigned order == float order) with the child's
+// slot number in the two lowest mantissa bits, or kMissKey | slot on a miss.  One v_min_u32 / v_max_u32 pair then is a
+// compare-exchange of (distance, child) -- no separate payload to move -- and the reference is rebuilt from the slot
+// number after sorting.  The 2 bits perturb the ORDER of children whose distances agree to 22 bits, nothing else.
+constexpr uint32_t kMissKey = 0xFFFFFFFCu;
+template <int K, int J>
+DMT_DEV void slab_keys(uint32_t nqx, uint32_t nqy, uint32_t nqz, uint32_t fqx, uint32_t fqy, uint32_t fqz, f3 a, f3 b, float tlimit,
+                       uint32_t& keyK, uint32_t& keyJ) {
+  // children K and J side by side in packed registers: six v_pk_fma_f32 instead of twelve v_fma_f32
+  v2f const tnx = fma_(v2f{qbyte<K>(nqx), qbyte<J>(nqx)}, a.x, v2f{b.x, b.x});
+  v2f const tny = fma_(v2f{qbyte<K>(nqy), qbyte<J>(nqy)}, a.y, v2f{b.y, b.y});
+  v2f const tnz = fma_(v2f{qbyte<K>(nqz), qbyte<J>(nqz)}, a.z, v2f{b.z, b.z});
+  v2f const tfx = fma_(v2f{qbyte<K>(fqx), qbyte<J>(fqx)}, a.x, v2f{b.x, b.x});
+  v2f const tfy = fma_(v2f{qbyte<K>(fqy), qbyte<J>(fqy)}, a.y, v2f{b.y, b.y});
+  v2f const tfz = fma_(v2f{qbyte<K>(fqz), qbyte<J>(fqz)}, a.z, v2f{b.z, b.z});
+  float const tnK = fmaxf(fmaxf(fmaxf(tnx.x, tny.x), tnz.x), 0.f), tnJ = fmaxf(fmaxf(fmaxf(tnx.y, tny.y), tnz.y), 0.f);
+  float const tfK = fminf(fminf(fminf(tfx.x, tfy.x), tfz.x), tlimit), tfJ = fminf(fminf(fminf(tfx.y, tfy.y), tfz.y), tlimit);
+  keyK = tnK <= tfK ? ((__float_as_uint(tnK) & ~3u) | uint32_t(K)) : (kMissKey | uint32_t(K));
+  keyJ = tnJ <= tfJ ? ((__float_as_uint(tnJ) & ~3u) | uint32_t(J)) : (kMissKey | uint32_t(J));
+}
+DMT_DEV void kswap(uint32_t& a, uint32_t& b) {
+  uint32_t const lo = a < b ? a : b, hi = a < b ? b : a;  // v_min_u32 / v_max_u32
+  a = lo, b = hi;
 }
 // node step: cur is an inner node
 template <bool STATS = false>
@@ -167,23 +181,27 @@ DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc =
   uint32_t const nqx = tv.sr.negx ? w1.w : w1.z, fqx = tv.sr.negx ? w1.z : w1.w;
   uint32_t const nqy = tv.sr.negy ? w2.y : w2.x, fqy = tv.sr.negy ? w2.x : w2.y;
   uint32_t const nqz = tv.sr.negz ? w2.w : w2.z, fqz = tv.sr.negz ? w2.z : w2.w;
-  uint32_t const inner = (meta >> 24) & 0xFu, count = meta >> 28;
-  float k0 = slab_q<0>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, count);
-  float k1 = slab_q<1>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, count);
-  float k2 = slab_q<2>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, count);
-  float k3 = slab_q<3>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, count);
-  // implicit references: child k < inner is node childBase + k, else leaf leafBase + (k - inner)
-  uint32_t const lb = w1.y - inner;  // wraps when leafBase < inner; lb + k is exact again for every k >= inner
-  uint32_t r0 = 0u < inner ? w1.x : (lb | kBvhLeafFlag);
-  uint32_t r1 = 1u < inner ? w1.x + 1u : ((lb + 1u) | kBvhLeafFlag);
-  uint32_t r2 = 2u < inner ? w1.x + 2u : ((lb + 2u) | kBvhLeafFlag);
-  uint32_t r3 = 3u < inner ? w1.x + 3u : ((lb + 3u) | kBvhLeafFlag);
-  cswap(k0, r0, k1, r1);
-  cswap(k2, r2, k3, r3);
-  cswap(k0, r0, k2, r2);
-  cswap(k1, r1, k3, r3);
-  cswap(k1, r1, k2, r2);
-  bool const p3 = k3 < kInf, p2 = k2 < kInf, p1 = k1 < kInf, p0 = k0 < kInf;
+  // An empty slot holds the inverted box (lo 255, hi 0): on every axis with a finite slope its near plane lies a whole
+  // 255 * |a| behind its far plane, so it misses by itself (the builder keeps every scale >= 2^-60, so a never
+  // flushes to zero).  No widening of the exit distance either: the builder's padding exceeds the slab arithmetic's
+  // rounding by more than an order of magnitude (header).
+  uint32_t k0, k1, k2, k3;
+  slab_keys<0, 1>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, k0, k1);
+  slab_keys<2, 3>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, k2, k3);
+  kswap(k0, k1);
+  kswap(k2, k3);
+  kswap(k0, k2);
+  kswap(k1, k3);
+  kswap(k1, k2);
+  // implicit references: slot s < inner is node childBase + s, else leaf leafBase + (s - inner)
+  uint32_t const inner = (meta >> 24) & 0xFu;
+  uint32_t const lb = w1.y - inner;  // may wrap below zero; + slot (>= inner) is exact again modulo 2^32
+  auto ref_of = [&](uint32_t key) {
+    uint32_t const slot = key & 3u;
+    return slot < inner ? w1.x + slot : ((lb + slot) | kBvhLeafFlag);
+  };
+  uint32_t const r0 = ref_of(k0), r1 = ref_of(k1), r2 = ref_of(k2), r3 = ref_of(k3);
+  bool const p3 = k3 < kMissKey, p2 = k2 < kMissKey, p1 = k1 < kMissKey, p0 = k0 < kMissKey;
   if constexpr (STATS) tc->deadNodes += p0 ? 0u : 1u;
   if (!__any(tv.stack.sp > kBvhLdsStack - 3)) {
     // whole wave within the LDS part of the stack: branch-free.  All three candidates are written, far to

@@ -694,6 +694,16 @@ DMT_DEV void film_store(float4* p, float4 v) {
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One sample into a pixel's running statistics: SMEMLayout::updateSample, T/megakernel/megakernel.cuh:59-79.  ONE function
+// for every fold in this library (megakernel items, wavefront passes), so that every path to the film rounds alike.
+DMT_DEV void welford_update(f3& mean, f3& M2, float& N, f3 L) {
+  N = N + 1.0f;
+  f3 const delta = L - mean;
+  mean = mean + delta / N;
+  f3 const delta2 = L - mean;
+  M2 = M2 + delta * delta2;
+}
+
 DMT_DEV void item_fold(KArgs Pk, uint32_t gtid, int lane, uint32_t seq) {
   TileArgs const T = load_tile_args(Pk);
   uint32_t const slot = seq & 1u;
@@ -724,14 +734,7 @@ DMT_DEV void item_fold(KArgs Pk, uint32_t gtid, int lane, uint32_t seq) {
     float N = v.w;
     float const* p = stage_slab(Pk, gtid, slot) + uint32_t(lane) * 3u;
 #pragma unroll 8
-    for (uint32_t k = 0; k < n; ++k, p += 192) {  // SMEMLayout::updateSample, megakernel.cuh:59-79
-      f3 const L = mk3(p[0], p[1], p[2]);
-      N = N + 1.0f;
-      f3 const delta = L - mean;
-      mean = mean + delta / N;
-      f3 const delta2 = L - mean;
-      M2 = M2 + delta * delta2;
-    }
+    for (uint32_t k = 0; k < n; ++k, p += 192) welford_update(mean, M2, N, mk3(p[0], p[1], p[2]));
     film_store(T.mean + pidx, make_float4(mean.x, mean.y, mean.z, 0.f));  // endSample, megakernel.cuh:81-85
     film_store(T.m2 + pidx, make_float4(M2.x, M2.y, M2.z, N));
   }
@@ -957,6 +960,11 @@ DMT_DEV void megakernel_body_bvh() {
         if (__popcll(__ballot(tv.phase == TR_DONE)) >= DMT_BVH_SHADE_THRESHOLD) break;
         // (parking a found leaf and carrying on with node steps -- bvh_device.hpp trav_park_leaf -- was measured here:
         //  8 % fewer wave iterations but 5 % slower, the extra dependent LDS pop lengthens every node step)
+#ifdef DMT_BVH_BOTH_STEPS  // experiment: every traversing lane advances every iteration (node and leaf code both run)
+        if constexpr (STATS) ++ls.itNode, ++ls.itLeaf, ls.lanesLeaf += onLeaf ? 1u : 0u;
+        if (onNode) trav_node<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
+        if (onLeaf) trav_leaf<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
+#else
         if (nNode * DMT_BVH_NODE_WEIGHT >= nLeaf * DMT_BVH_LEAF_WEIGHT) {
           if constexpr (STATS) ++ls.itNode;
           if (onNode) trav_node<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
@@ -964,6 +972,7 @@ DMT_DEV void megakernel_body_bvh() {
           if constexpr (STATS) ++ls.itLeaf, ls.lanesLeaf += onLeaf ? 1u : 0u;
           if (onLeaf) trav_leaf<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
         }
+#endif
       }
       // D. resolve + shade every lane that has finished its round
       if constexpr (STATS) ++ls.itShade, ls.lanesShade += tv.phase == TR_DONE ? 1u : 0u;
@@ -995,6 +1004,8 @@ __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_area(RenderParams P) 
 // both optional light kinds at once
 __global__ void __launch_bounds__(256, 4) k_megakernel_env_area(RenderParams P) { megakernel_body<false, false, true, true>(); }
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_env_area(RenderParams P) { megakernel_body_bvh<false, true, true>(); }
+
+#include "wavefront.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // device unit-test kernels
@@ -1243,6 +1254,14 @@ struct dmt_ctx {
   int bvhDepth = 0;
   uint32_t bvhNodeCount = 0, bvhPairCount = 0;
   int blocksPerCUBvh = 0;
+  // wavefront form of the BVH path (wavefront.hpp)
+  int bvhStrategy = 0;             // 0 = automatic (by launch size), 1 = megakernel, 2 = wavefront
+  size_t wfTargetPaths = size_t(1) << 22;  // path slots per pass
+  float* d_wfState = nullptr;
+  uint32_t* d_wfQueue = nullptr;   // two queues
+  uint32_t* d_wfCounts = nullptr;  // counts + cursors
+  size_t wfSlotsCap = 0, wfCountsCap = 0;
+  int wfBlocksTrace = 0, wfBlocksShade = 0;
   int blocksPerCUEnv = 0, blocksPerCUBvhEnv = 0;
   float* d_env = nullptr;  // A18: one allocation holding the five tables and the image
   EnvView env{};           // env.w == 0: no env map
@@ -1544,6 +1563,14 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<void const*>(k_megakernel_bvh_area), 256, 0);
     ctx->blocksPerCUArea = a > 0 ? a : 1, ctx->blocksPerCUBvhArea = b > 0 ? b : 1;
   }
+  if (char const* e3 = std::getenv("DMT_BVH_STRATEGY")) {  // experiments: 0 auto, 1 megakernel, 2 wavefront
+    int const v = std::atoi(e3);
+    ctx->bvhStrategy = v < 0 || v > 2 ? 0 : v;
+  }
+  if (char const* e4 = std::getenv("DMT_WF_PATHS")) {
+    long long const v = std::atoll(e4);
+    if (v >= 4096) ctx->wfTargetPaths = size_t(v);
+  }
   if (char const* e2 = std::getenv("DMT_SUB_SHIFT")) {  // scheduling experiments only: results do not depend on it
     int const v = std::atoi(e2);
     ctx->subShift = v < 0 ? -1 : (v > 2 ? 2 : v);
@@ -1575,6 +1602,9 @@ int dmt_ctx_destroy(dmt_ctx* ctx) {
   (void)hipFree(ctx->d_bvhNodes);
   (void)hipFree(ctx->d_trisBvh);
   (void)hipFree(ctx->d_overflow);
+  (void)hipFree(ctx->d_wfState);
+  (void)hipFree(ctx->d_wfQueue);
+  (void)hipFree(ctx->d_wfCounts);
   if (ctx->ownFilm) {
     (void)hipFree(ctx->d_mean);
     (void)hipFree(ctx->d_m2);
@@ -1715,6 +1745,14 @@ int dmt_set_accel(dmt_ctx* ctx, int mode) {
   return DMT_OK;
 }
 
+int dmt_set_bvh_strategy(dmt_ctx* ctx, int strategy, uint64_t paths_per_pass) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if (strategy < 0 || strategy > 2) return fail(ctx, DMT_ERR_INVALID, "dmt_set_bvh_strategy: 0 = automatic, 1 = megakernel, 2 = wavefront");
+  ctx->bvhStrategy = strategy;
+  if (paths_per_pass) ctx->wfTargetPaths = size_t(paths_per_pass);
+  return DMT_OK;
+}
+
 int dmt_set_partition(dmt_ctx* ctx, int rank, int world) {
   if (!ctx) return DMT_ERR_INVALID;
   if (world < 1 || rank < 0 || rank >= world) return fail(ctx, DMT_ERR_INVALID, "dmt_set_partition: bad rank/world");
@@ -1772,6 +1810,108 @@ int dmt_download_film(dmt_ctx* ctx, float* mean4, float* m24) {
   return DMT_OK;
 }
 
+// Wavefront form of a BVH launch (wavefront.hpp): passes over (owned tiles, sample range), each pass a fixed sequence of
+// kernels on the context's stream.  `ownedTiles` = tiles this rank renders; P carries region / partition / film.
+static int launchWavefront(dmt_ctx* ctx, RenderParams P, uint32_t ownedTiles, uint32_t sample_offset, uint32_t spp, bool useEnv,
+                           bool useArea, uint64_t* stats, int nstats) {
+  uint32_t const iters = uint32_t(ctx->maxDepth) + 2u;  // closest rays at depth 0..maxDepth, + one trailing shadow ray
+  size_t const target = ctx->wfTargetPaths < 4096 ? 4096 : ctx->wfTargetPaths;
+  uint32_t const tilesPerPass = uint32_t(std::min<size_t>(ownedTiles, std::max<size_t>(1, target / 64)));
+  uint32_t n = uint32_t(std::max<size_t>(1, target / (size_t(tilesPerPass) * 64)));
+  if (n > spp) n = spp;
+  size_t const slotsMax = size_t(tilesPerPass) * 64 * n;
+  if (slotsMax > ctx->wfSlotsCap) {
+    (void)hipFree(ctx->d_wfState), (void)hipFree(ctx->d_wfQueue);
+    ctx->d_wfState = nullptr, ctx->d_wfQueue = nullptr, ctx->wfSlotsCap = 0;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_wfState), size_t(WF_PLANES) * slotsMax * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_wfQueue), 2 * slotsMax * sizeof(uint32_t)));
+    ctx->wfSlotsCap = slotsMax;
+  }
+  size_t const nCounts = 2 * (size_t(iters) + 2);
+  if (nCounts > ctx->wfCountsCap) {
+    (void)hipFree(ctx->d_wfCounts);
+    ctx->d_wfCounts = nullptr, ctx->wfCountsCap = 0;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_wfCounts), nCounts * sizeof(uint32_t)));
+    ctx->wfCountsCap = nCounts;
+  }
+  if (ctx->wfBlocksTrace == 0) {
+    int a = 0, b = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<void const*>(k_wf_trace), 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<void const*>(k_wf_shade_env_area), 256, 0);
+    ctx->wfBlocksTrace = a > 0 ? a : 1, ctx->wfBlocksShade = b > 0 ? b : 1;
+  }
+  uint32_t const traceBlocks = uint32_t(ctx->cuCount) * uint32_t(stats ? 4 : ctx->wfBlocksTrace);
+  uint32_t const shadeBlocks = uint32_t(ctx->cuCount) * uint32_t(stats ? 2 : ctx->wfBlocksShade);
+  int const rcO = ensureOverflow(ctx, size_t(traceBlocks) * 256);
+  if (rcO) return rcO;
+  P.bvh = bvhView(ctx, size_t(traceBlocks) * 256);
+  unsigned long long* dstats = nullptr;
+  if (stats) {
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dstats), 16 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(dstats, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    P.stats = dstats;
+  }
+  WfParams W{};
+  W.state = ctx->d_wfState;
+  W.queue[0] = ctx->d_wfQueue, W.queue[1] = ctx->d_wfQueue + slotsMax;
+  W.counts = ctx->d_wfCounts, W.cursors = ctx->d_wfCounts + (iters + 2);
+  for (uint32_t tile0 = 0; tile0 < ownedTiles; tile0 += tilesPerPass) {
+    uint32_t const tiles = std::min(tilesPerPass, ownedTiles - tile0);
+    for (uint32_t s = 0; s < spp; s += n) {
+      W.tile0 = tile0, W.pixelSlots = tiles * 64u, W.s0 = sample_offset + s, W.n = std::min(n, spp - s);
+      W.slots = W.pixelSlots * W.n;
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_wfCounts, 0, nCounts * sizeof(uint32_t), ctx->stream));
+      uint32_t const genBlocks = std::min<uint32_t>((W.slots + 255u) / 256u, uint32_t(ctx->cuCount) * 8u);
+      W.it = 0;
+      hipLaunchKernelGGL(k_wf_generate, dim3(genBlocks), dim3(256), 0, ctx->stream, P, W);
+      for (uint32_t it = 0; it < iters; ++it) {
+        W.it = it;
+        // a persistent grid no larger than the pass: small passes do not pay for 2 048 idle blocks per launch
+        uint32_t const tb = std::min<uint32_t>(traceBlocks, (W.slots + 255u) / 256u);
+        uint32_t const sb = std::min<uint32_t>(shadeBlocks, (W.slots + 255u) / 256u);
+        if (stats) {
+          hipLaunchKernelGGL(k_wf_trace_stats, dim3(tb), dim3(256), 0, ctx->stream, P, W);
+          if (useEnv)
+            hipLaunchKernelGGL(k_wf_shade_stats_env, dim3(sb), dim3(256), 0, ctx->stream, P, W);
+          else
+            hipLaunchKernelGGL(k_wf_shade_stats, dim3(sb), dim3(256), 0, ctx->stream, P, W);
+          continue;
+        }
+        hipLaunchKernelGGL(k_wf_trace, dim3(tb), dim3(256), 0, ctx->stream, P, W);
+        if (useEnv && useArea)
+          hipLaunchKernelGGL(k_wf_shade_env_area, dim3(sb), dim3(256), 0, ctx->stream, P, W);
+        else if (useArea)
+          hipLaunchKernelGGL(k_wf_shade_area, dim3(sb), dim3(256), 0, ctx->stream, P, W);
+        else if (useEnv)
+          hipLaunchKernelGGL(k_wf_shade_env, dim3(sb), dim3(256), 0, ctx->stream, P, W);
+        else
+          hipLaunchKernelGGL(k_wf_shade, dim3(sb), dim3(256), 0, ctx->stream, P, W);
+      }
+      if (!stats) hipLaunchKernelGGL(k_wf_fold, dim3((W.pixelSlots + 255u) / 256u), dim3(256), 0, ctx->stream, P, W);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
+  if (stats) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    std::vector<unsigned long long> h(16, 0);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), dstats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(dstats);
+    HIP_TRY(ctx, e);
+    {  // samples = pixels of the owned tiles inside the region x spp (the kernels count rays, visits and bounces)
+      uint64_t pixels = 0;
+      for (uint32_t item = 0; item < ownedTiles; ++item) {
+        uint32_t const j = uint32_t(P.rank) + item * uint32_t(P.world);
+        int const px0 = (P.tx0 + int(j % uint32_t(P.rtx))) * 8, py0 = (P.ty0 + int(j / uint32_t(P.rtx))) * 8;
+        int const w = std::min(px0 + 8, P.x1) - std::max(px0, P.x0), hgt = std::min(py0 + 8, P.y1) - std::max(py0, P.y0);
+        if (w > 0 && hgt > 0) pixels += uint64_t(w) * uint64_t(hgt);
+      }
+      h[0] = pixels * spp;
+    }
+    for (int k = 0; k < nstats && k < 16; ++k) stats[k] = h[size_t(k)];
+  }
+  return DMT_OK;
+}
+
 static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1, uint64_t* stats6, int nstats) {
   if (!ctx) return DMT_ERR_INVALID;
   if (stats6) memset(stats6, 0, size_t(nstats) * sizeof(uint64_t));
@@ -1807,6 +1947,10 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   P.sampleOffset = sample_offset, P.spp = spp;
   P.maxDepth = ctx->maxDepth;
   if (P.numItems == 0) return DMT_OK;
+  uint32_t const ownedTiles = P.numItems;
+  // BVH launches run as the megakernel unless the wavefront form (wavefront.hpp) is asked for: on the measured scenes
+  // the megakernel is faster (1 M triangles: 489 vs 378 Msamples/s), so "automatic" means megakernel
+  bool const wavefront = ctx->accel == DMT_ACCEL_BVH && ctx->bvhStrategy == 2;
   {  // fewer owned tiles than ~4 per resident wave: schedule row bands of the tiles instead of whole tiles
     uint32_t const waves = uint32_t(ctx->cuCount) * uint32_t(blocksPerCuOf(ctx)) * 4u;
     P.subShift = ctx->subShift >= 0 ? uint32_t(ctx->subShift) : 0u;
@@ -1862,7 +2006,12 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
   if (P.numChunks > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->d_tileDone, 0, size_t(P.numItems) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
-  if (useBvh) {
+  if (useBvh && wavefront) {
+    if (!ctx->haveBvh) return fail(ctx, DMT_ERR_STATE, "dmt_render: BVH not built");
+    int const rcW = launchWavefront(ctx, P, ownedTiles, sample_offset, spp, useEnv, useArea, stats6, nstats);
+    if (rcW) return rcW;
+    if (stats6) return DMT_OK;
+  } else if (useBvh) {
     if (!ctx->haveBvh) return fail(ctx, DMT_ERR_STATE, "dmt_render: BVH not built");
     int const rcO = ensureOverflow(ctx, size_t(ctx->cuCount) * size_t(blocksPerCuOf(ctx) > ctx->blocksPerCUBvh ? blocksPerCuOf(ctx) : ctx->blocksPerCUBvh) * 256);
     if (rcO) return rcO;

@@ -90,6 +90,11 @@ int dmt_set_camera(dmt_ctx* ctx, const dmt_camera* cam);
 /* depth cap of the bounce loop; the reference hard-codes 32 (megakernel.cu:154) */
 int dmt_set_limits(dmt_ctx* ctx, int max_depth);
 int dmt_set_accel(dmt_ctx* ctx, int mode);
+/* How DMT_ACCEL_BVH launches are executed (results are bit-identical either way): 0 = automatic = 1 = the megakernel
+ * (fastest on every measured scene); 2 = the device-side wavefront -- generate / trace / shade / fold kernels over
+ * path-state arrays in HBM, csrc/wavefront.hpp -- kept as a measured alternative.  paths_per_pass: path
+ * slots of one wavefront pass (0 = keep; default 2^22, 144 bytes of state each; more is faster, up to ~2^27). */
+int dmt_set_bvh_strategy(dmt_ctx* ctx, int strategy, uint64_t paths_per_pass);
 /* tile partition for multi-GPU rendering: this context renders only the 8x8-pixel tiles whose
  * index (row-major over the tile grid) is congruent to `rank` modulo `world`.  Default 0 of 1. */
 int dmt_set_partition(dmt_ctx* ctx, int rank, int world);

@@ -536,6 +536,55 @@ def test_bvh_million_triangles(renderer, pkg, O):
     renderer.set_accel(0)
 
 
+@pytest.mark.parametrize("kind", ["plain", "env", "area", "env_area", "partition"])
+def test_bvh_wavefront_equals_megakernel(renderer, pkg, O, kind):
+    """DMT_ACCEL_BVH launches run as a megakernel (small launches) or as the device-side wavefront of csrc/wavefront.hpp
+    (generate / trace / shade / fold kernels over path-state arrays).  Same samples, same arithmetic (the wavefront's
+    shading IS the megakernel's path_shade), same fold order: the films must be bit-identical, for every light kind, for
+    passes that split tiles as well as samples, with a region off the tile grid, with a tile partition, and resumable."""
+    spp, depth, region, part = 24, 8, None, (0, 1)
+    if kind == "plain":
+        sc = pkg.host_scene.random_triangle_scene(6000, width=200, height=136)
+        region = (3, 5, 197, 131)
+    elif kind == "partition":
+        sc = pkg.host_scene.random_triangle_scene(6000, width=200, height=136)
+        part = (1, 3)
+    elif kind == "env":
+        sc = pkg.host_scene.sphere_envmap_scene(96, 96, lat=8, lon=16, env_height=16)
+    else:
+        sc = O.cornell_box(72, 72)
+        sc.lights = sc.lights[:0] if kind == "area" else sc.lights
+        for a in (sc.xs, sc.ys, sc.zs):
+            a[[0, 1, 16, 17]] = a[[0, 1, 16, 17]][:, [0, 2, 1, 3]]
+        sc.set_area_lights([0, 1, 16, 17, 20, 21], [[6, 6, 5], [6, 6, 5], [12, 14, 20], [12, 14, 20], [20, 15, 10], [20, 15, 10]])
+        if kind == "env_area":
+            sc.env_rgb, sc.env_quat, sc.env_scale = pkg.host_scene.synthetic_sky(16), np.array([0, 0, 0, 1], np.float32), 1.0
+        depth = 6
+    renderer.upload_scene(sc)
+    renderer.set_limits(depth)
+    renderer.set_accel(1)
+    renderer.set_partition(*part)
+    films = []
+    try:
+        for strategy, paths in ((1, 0), (2, 1 << 22), (2, 20000)):   # megakernel; wavefront in one pass; in many (tile x sample) passes
+            renderer.set_bvh_strategy(strategy, paths)
+            renderer.film_clear()
+            renderer.render(spp - 7, region=region)
+            renderer.render(7, sample_offset=spp - 7, region=region)       # resumable
+            renderer.sync()
+            films.append(renderer.download_film())
+    finally:
+        renderer.set_bvh_strategy(0, 1 << 22)
+        renderer.set_accel(0)
+        renderer.set_partition(0, 1)
+        renderer.clear_envmap()
+        renderer.upload_area_lights([], np.zeros((0, 3), np.float32))
+    assert films[0][0][..., :3].max() > 0 and films[0][1][..., 3].max() == spp
+    for f in films[1:]:
+        assert np.array_equal(films[0][1][..., 3], f[1][..., 3])
+        assert np.array_equal(films[0][0], f[0]) and np.array_equal(films[0][1], f[1])
+
+
 def test_bvh_overflow_stack_variant(renderer):
     """The traversal stack keeps 16 entries per lane in LDS and the rest in a global overflow area that ordinary scenes
     rarely reach.  csrc/variants/libdmt_hip_stack2.so is the same library compiled with 2 LDS entries: every non-trivial
