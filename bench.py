@@ -60,7 +60,8 @@ WORKLOADS = {
     # BASELINE configs[3]: 1 M random triangles (SURVEY 8d generator); BVH traversal.  102 MB of nodes + leaves:
     # resident in the 256 MiB Infinity Cache
     "random1M_1024x1024_512spp_8bounces": (1024, 1024, 512, 8, "random1M"),
-    # the same generator at 16 M triangles: nodes + leaves (1.6 GB) exceed the Infinity Cache -> the HBM-roofline point
+    # the same generator at 16 M triangles and the SAME density (the cube of centroids 16^(1/3) times wider): nodes +
+    # leaves (0.96 GB) are four times the 256 MiB Infinity Cache -> the HBM-footprint point
     "random16M_1024x1024_64spp_8bounces": (1024, 1024, 64, 8, "random16M"),
     # BASELINE configs[2] on its named assets: the reference's scenes/sphere.fbx under scenes/veranda_polyhaven_1k.png,
     # scene description scenes/fbx_example.json (committed as data under tests/golden/c3/), film 256x256 as the JSON says
@@ -70,7 +71,7 @@ WORKLOADS = {
     # BASELINE configs[4]: the frame the reference quotes for 8 GPUs; runs on any N (strong scaling)
     "cornell_4096x4096_4096spp_8bounces": (4096, 4096, 4096, 8, "cornell"),
 }
-RANDOM_SCENE_TRIANGLES = {"random1M": 1_000_000, "random16M": 16_000_000}
+RANDOM_SCENE_TRIANGLES = {"random1M": (1_000_000, 1.0), "random16M": (16_000_000, 16.0 ** (1.0 / 3.0))}
 BVH_NODE_BYTES = 64            # csrc/bvh.hpp Bvh4Node: one 64-byte sector (48 bytes read)
 BVH_LEAF_BYTES_PER_TRI = 40    # csrc/bvh.hpp TriPair: 80 B per pair
 DEFAULT_WORKLOAD = "cornell_1024x1024_1024spp_8bounces"
@@ -201,7 +202,8 @@ def build_scene(pkg, scene_kind, width, height):
         s = hs.load_json(ROOT / "tests" / "golden" / "c3" / "c3_sphere_veranda.json")
         assert (s.width, s.height) == (width, height)
         return s
-    return hs.random_triangle_scene(RANDOM_SCENE_TRIANGLES[scene_kind], width=width, height=height)
+    count, extent = RANDOM_SCENE_TRIANGLES[scene_kind]
+    return hs.random_triangle_scene(count, width=width, height=height, extent=extent)
 
 
 def main():
@@ -266,6 +268,12 @@ def main():
         film.zero_()
         for s0 in range(0, spp, kspp):
             r.render(min(kspp, spp - s0), sample_offset=s0)
+        if world > 1 and backend != "nccl":
+            # gloo rehearsal (ranks SHARE one GPU): gloo stages the device tensor through the host in many small stream
+            # operations; issued while the other ranks' persistent kernels hold the GPU, each of them waits for a time
+            # slice of the shared device (4 ranks: 71 s per step instead of 0.35 s).  Draining the stream first lets them
+            # run back to back.  Not needed, and not done, on the RCCL path (one GPU per rank, stream-ordered collective).
+            torch.cuda.synchronize(dev)
         pkg.multigpu.combine_films(mean, m2, dst=0, film=film)  # disjoint tiles + zero frames: SUM-reduce == exact gather
 
     def barrier():
@@ -320,23 +328,26 @@ def main():
                 if getattr(scene, "env_rgb", None) is not None:
                     oscene.set_envmap(scene.env_rgb, scene.env_quat, scene.env_scale)
                 threads = int(os.environ.get("DMT_CPU_THREADS", min(os.cpu_count() or 1, 16)))
-                y = height // 2
-                # bounded sample: ~2e9 triangle tests
-                npx = int(max(16, min(width, 2e9 / max(1, scene.tri_count) / 8)))
-                ospp = 1 if scene.tri_count > 100_000 else min(spp, 64)
-                x0 = width // 2 - npx // 2
+                # bounded sample: ~1e10 triangle tests (10-20 s on 16 host threads), from the GPU's own ray counters
+                rays = (stats["closest_rays"] + stats["shadow_rays"]) / max(1.0, stats["samples"])
+                want = max(16.0, 1e10 / max(1.0, rays * scene.tri_count))
+                ospp = int(min(spp, max(1, want // width)))
+                npx = int(min(width, max(16, want // ospp)))
+                nrows = int(min(height, max(1, round(want / (ospp * npx)))))
+                x0, y = width // 2 - npx // 2, height // 2 - nrows // 2
                 tc = time.perf_counter()
-                omean, om2, ost = O.render(oscene, ospp, max_depth=max_depth, region=(x0, y, x0 + npx, y + 1),
+                omean, om2, ost = O.render(oscene, ospp, max_depth=max_depth, region=(x0, y, x0 + npx, y + nrows),
                                            threads=threads, want_stats=True)
                 tcpu = time.perf_counter() - tc
                 cpu_baseline = {
                     "value": round(ost["samples"] / tcpu / 1e6, 8), "unit": "Msamples/s", "cores": threads, "kind": "port",
                     "cpu": cpu_model(),
-                    "sample": f"{npx} pixels x {ospp} spp of row {y} ({tcpu:.1f} s); the reference arithmetic is a brute-force loop "
-                              f"over all {scene.tri_count:,} triangles per ray (megakernel.cu:121-133), no BVH",
+                    "sample": f"{npx} x {nrows} pixels x {ospp} spp around the frame centre ({ost['samples']} samples, {tcpu:.1f} s); the "
+                              f"reference arithmetic is a brute-force loop over all {scene.tri_count:,} triangles per ray "
+                              f"(megakernel.cu:121-133), no BVH",
                 }
                 if ospp == spp:
-                    d = film_mean[y:y + 1, x0:x0 + npx, :3].astype(np.float64) - omean[y:y + 1, x0:x0 + npx, :3]
+                    d = film_mean[y:y + nrows, x0:x0 + npx, :3].astype(np.float64) - omean[y:y + nrows, x0:x0 + npx, :3]
                     parity = {"rmse_vs_cpu_rows": float(np.sqrt((d ** 2).mean(axis=2)).mean()), "tolerance": 1e-3}
         elif not args.no_cpu_baseline and world == 1:
             O = graft.load_oracle()          # cpu_baseline leg: the oracle is the thing timed
@@ -381,7 +392,7 @@ def main():
         scene_text = {
             "cornell": "cornellBox() (26 triangles, spot + constant env)",
             "random1M": "1,000,000 random triangles, splitmix64 seed 0x5EED1234 (SURVEY 8d), Cornell BSDFs, spot + env",
-            "random16M": "16,000,000 random triangles, same generator: BVH nodes + leaves exceed the 256 MiB Infinity Cache",
+            "random16M": "16,000,000 random triangles, same generator and density (cube of centroids 2.52x wider): BVH nodes + leaves = 0.96 GB, four times the 256 MiB Infinity Cache",
             "c3_assets": f"the reference's scenes/sphere.fbx ({scene.tri_count} triangles, GGX conductor) under "
                          "scenes/veranda_polyhaven_1k.png as importance-sampled env map (A18), spot light; scenes/fbx_example.json, "
                          "mesh in metres (tests/test_configs_gpu.py docstring)",

@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <map>
 #include <string>
@@ -83,7 +84,12 @@ struct Reader {
           o += 12;
           if (o + clen > d.size()) return err = "truncated array", false;
           size_t const esz = p.type == 'f' || p.type == 'i' ? 4 : (p.type == 'b' ? 1 : 8);
-          std::vector<unsigned char> raw(size_t(n) * esz);
+          // the element count comes from the file: bound it by what the stored bytes can possibly hold BEFORE allocating
+          // (raw: exactly clen bytes; deflate expands at most ~1032:1) and by an absolute limit of 2^28 elements
+          uint64_t const need = uint64_t(n) * esz;
+          if (n > (1u << 28) || (enc == 0 && need != clen) || (enc == 1 && need > uint64_t(clen) * 1032u + 64u) || enc > 1)
+            return err = "array size inconsistent with its stored bytes", false;
+          std::vector<unsigned char> raw(static_cast<size_t>(need), 0);
           if (enc == 1) {
             uLongf len = uLongf(raw.size());
             if (uncompress(raw.data(), &len, &d[o], clen) != Z_OK || len != raw.size()) return err = "bad deflate stream in array", false;
@@ -110,7 +116,7 @@ struct Reader {
     return true;
   }
   // returns 0 on the null record, else the end offset; fills `n`
-  bool readNode(size_t o, Node& n, size_t& end, int depth) {
+  bool readNode(size_t o, Node& n, size_t& end, int depth, size_t parentEnd) {
     if (depth > 64) return err = "nesting too deep", false;
     uint64_t e = 0, np = 0, pl = 0;
     size_t hdr;
@@ -124,7 +130,7 @@ struct Reader {
       e = a, np = b, pl = c, hdr = 12;
     }
     if (e == 0) return end = 0, true;
-    if (e > d.size() || e <= o) return err = "bad record end offset", false;
+    if (e > d.size() || e <= o || e > parentEnd) return err = "bad record end offset", false;
     uint8_t nl;
     if (!get(o + hdr, nl)) return false;
     size_t p = o + hdr + 1;
@@ -138,7 +144,7 @@ struct Reader {
     while (p < e) {
       Node c;
       size_t ce = 0;
-      if (!readNode(p, c, ce, depth + 1)) return false;
+      if (!readNode(p, c, ce, depth + 1, size_t(e))) return false;
       if (ce == 0) break;  // null record
       n.children.push_back(std::move(c));
       p = ce;
@@ -163,7 +169,7 @@ bool prop70(Node const& owner, char const* name, double* out, int n) {
 
 }  // namespace
 
-bool readFbxMesh(std::string const& path, std::vector<Triangle>& out, std::string* error) {
+static bool readFbxMeshImpl(std::string const& path, std::vector<Triangle>& out, std::string* error) {
   auto bad = [&](std::string const& m) {
     if (error) *error = path + ": " + m;
     return false;
@@ -181,7 +187,7 @@ bool readFbxMesh(std::string const& path, std::vector<Triangle>& out, std::strin
   for (size_t o = 27; o + (r.wide ? 25 : 13) <= r.d.size();) {
     Node n;
     size_t end = 0;
-    if (!r.readNode(o, n, end, 0)) return bad(r.err);
+    if (!r.readNode(o, n, end, 0, r.d.size())) return bad(r.err);
     if (end == 0) break;
     root.children.push_back(std::move(n));
     o = end;
@@ -245,6 +251,19 @@ bool readFbxMesh(std::string const& path, std::vector<Triangle>& out, std::strin
   }
   if (out.empty()) return bad("mesh has no polygons");
   return true;
+}
+
+// Files are untrusted input: nothing escapes as an exception (allocation failure on a forged size, ...).
+bool readFbxMesh(std::string const& path, std::vector<Triangle>& out, std::string* error) {
+  try {
+    return readFbxMeshImpl(path, out, error);
+  } catch (std::exception const& e) {
+    if (error) *error = path + ": " + e.what();
+  } catch (...) {
+    if (error) *error = path + ": unknown error";
+  }
+  out.clear();
+  return false;
 }
 
 }  // namespace dmt_host

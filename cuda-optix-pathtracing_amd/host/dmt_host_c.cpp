@@ -22,6 +22,12 @@ dmt_host_scene* dmt_host_scene_random_triangles(uint64_t count, uint64_t seed) {
   if (h) h->s = randomTriangleScene(size_t(count), seed);
   return h;
 }
+dmt_host_scene* dmt_host_scene_random_triangles_ex(uint64_t count, uint64_t seed, float extent) {
+  if (!(extent > 0.f)) return nullptr;
+  auto* h = new (std::nothrow) dmt_host_scene();
+  if (h) h->s = randomTriangleScene(size_t(count), seed, extent);
+  return h;
+}
 // JSON front-end; on failure returns null and copies the message (NUL-terminated, truncated) into err
 dmt_host_scene* dmt_host_scene_load_json(const char* path, int* max_depth, int* samples_per_pixel, char* err, uint64_t err_cap) {
   auto* h = new (std::nothrow) dmt_host_scene();

@@ -299,7 +299,7 @@ Scene cornellBox() {
   return s;
 }
 
-Scene randomTriangleScene(size_t count, uint64_t seed) {
+Scene randomTriangleScene(size_t count, uint64_t seed, float extent) {
   Scene s = cornellBox();
   s.xs.clear(), s.ys.clear(), s.zs.clear(), s.matId.clear();
   uint64_t state = seed;
@@ -312,7 +312,8 @@ Scene randomTriangleScene(size_t count, uint64_t seed) {
   };
   s.xs.reserve(4 * count), s.ys.reserve(4 * count), s.zs.reserve(4 * count), s.matId.reserve(count);
   for (size_t i = 0; i < count; ++i) {
-    Vec3 const c{next01() * 20.f - 10.f, next01() * 20.f + 5.f, next01() * 20.f - 10.f};
+    // extent 1 = SURVEY 8(d)'s recipe: centroids uniform in the cube [-10,10] x [5,25] x [-10,10] in front of the camera
+    Vec3 const c{(next01() * 20.f - 10.f) * extent, next01() * 20.f * extent + 5.f, (next01() * 20.f - 10.f) * extent};
     Vec3 v[3];
     for (Vec3& p : v) p = add(c, {next01() * 0.3f - 0.15f, next01() * 0.3f - 0.15f, next01() * 0.3f - 0.15f});
     s.xs.insert(s.xs.end(), {v[0].x, v[1].x, v[2].x, 0.f});
@@ -321,7 +322,7 @@ Scene randomTriangleScene(size_t count, uint64_t seed) {
     s.matId.push_back(uint32_t(i % 7));
   }
   s.lights.clear();
-  s.lights.push_back(makeSpotLight({2.f, 2.f, 2.f}, {0, 15.f, 12.f}, {0, 0, -1}, cosf(PI / 6), cosf(PI / 3), 0.01f));
+  s.lights.push_back(makeSpotLight({2.f, 2.f, 2.f}, {0, 5.f + 10.f * extent, 10.f * extent + 2.f}, {0, 0, -1}, cosf(PI / 6), cosf(PI / 3), 0.01f));
   s.camera.width = 1024, s.camera.height = 1024;
   return s;
 }

@@ -84,7 +84,8 @@ Scene cornellBox();
 // BASELINE config 4 / SURVEY 8d: deterministic random triangle soup in front of the Cornell camera
 // (splitmix64 seed 0x5EED1234, centroids in [-10,10]^3 shifted to y in [5,25], edges in
 // [-0.15,0.15]^3, material = index mod 7 over the Cornell BSDFs, spot light at (0,15,12), env 0.1)
-Scene randomTriangleScene(size_t triangleCount, uint64_t seed = 0x5EED1234ull);
+// extent: edge length of the cube of centroids in units of the recipe's 20 (triangle size unchanged): count x extent^-3 is the density
+Scene randomTriangleScene(size_t triangleCount, uint64_t seed = 0x5EED1234ull, float extent = 1.f);
 
 // JSON scene front-end: the reference's scene description (src/core/private/core-parser.cpp:256-1455;
 // keys camera / film / textures / materials / objects / lights / envlight / transforms / world) flattened to the

@@ -16,13 +16,14 @@ def load_host_library():
         if not so.exists():
             raise RuntimeError(f"{so} is missing: run __graft_entry__.build()")
         lib = C.CDLL(str(so))
-        for name in ("dmt_host_scene_cornell_box", "dmt_host_scene_random_triangles", "dmt_host_scene_xs",
+        for name in ("dmt_host_scene_cornell_box", "dmt_host_scene_random_triangles", "dmt_host_scene_random_triangles_ex", "dmt_host_scene_xs",
                      "dmt_host_scene_ys", "dmt_host_scene_zs", "dmt_host_scene_mat_ids", "dmt_host_scene_bsdfs",
                      "dmt_host_scene_lights", "dmt_host_scene_infinite_lights", "dmt_host_scene_camera",
                      "dmt_host_scene_load_json", "dmt_host_scene_env_rgb", "dmt_host_scene_load_pbrt",
                      "dmt_host_scene_area_tri", "dmt_host_scene_area_le"):
             getattr(lib, name).restype = C.c_void_p
         lib.dmt_host_scene_random_triangles.argtypes = [C.c_uint64, C.c_uint64]
+        lib.dmt_host_scene_random_triangles_ex.argtypes = [C.c_uint64, C.c_uint64, C.c_float]
         lib.dmt_host_scene_triangle_count.restype = C.c_uint64
         for name in ("dmt_host_scene_bsdf_count", "dmt_host_scene_light_count", "dmt_host_scene_infinite_light_count"):
             getattr(lib, name).restype = C.c_uint32
@@ -133,8 +134,11 @@ def cornell_box(width=None, height=None):
     return s
 
 
-def random_triangle_scene(count, seed=0x5EED1234, width=None, height=None):
-    s = HostScene(load_host_library().dmt_host_scene_random_triangles(int(count), int(seed)))
+def random_triangle_scene(count, seed=0x5EED1234, width=None, height=None, extent=1.0):
+    """SURVEY 8(d) generator; extent scales the cube of centroids (density = count / extent^3 of the recipe's)."""
+    L = load_host_library()
+    s = HostScene(L.dmt_host_scene_random_triangles(int(count), int(seed)) if extent == 1.0 else
+                  L.dmt_host_scene_random_triangles_ex(int(count), int(seed), float(extent)))
     if width is not None:
         s.set_resolution(width, height if height is not None else width)
     return s

@@ -128,6 +128,29 @@ def test_c3_literal_scene_camera_inside_the_sphere(renderer, pkg, O):
     assert film_rmse(mean[y0:y1], om[y0:y1]) < RMSE_TOL
 
 
+@pytest.mark.parametrize("accel", [0, 1])
+def test_reference_scene_example_json(renderer, pkg, O, accel):
+    """The reference's scenes/scene_example.json unmodified (cube with a GGX dielectric under the veranda map), at the
+    file's own film and sample count, brute force and BVH: film vs the oracle on identical arrays."""
+    hs, osc = _load_c3(pkg, O, "scene_example.json")
+    renderer.upload_scene(hs)
+    renderer.set_limits(hs.max_depth)
+    renderer.set_accel(accel)
+    renderer.set_partition(0, 1)
+    try:
+        renderer.film_clear()
+        renderer.render(hs.spp)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
+    finally:
+        renderer.set_accel(0)
+        renderer.clear_envmap()
+    om, om2 = O.render(osc, hs.spp, max_depth=hs.max_depth, threads=16)[:2]
+    assert np.array_equal(m2[..., 3], om2[..., 3])
+    scale = float(om[..., :3].mean())
+    assert scale > 0.1 and film_rmse(mean, om) < RMSE_TOL * max(1.0, scale)
+
+
 def test_c5_frame_4096_reduced_spp(renderer, O):
     """BASELINE configs[4]'s frame on one GPU: 4096 x 4096, samples 4092..4095 (the last sample indices of the
     4096-spp run: largest Halton indices of the config), cap 8."""

@@ -143,6 +143,29 @@ def test_fbx_reader_rejects_garbage(pkg, tmp_path):
         pkg.host_scene.read_fbx(tmp_path / "b.fbx")
     with pytest.raises(ValueError, match="cannot open"):
         pkg.host_scene.read_fbx(tmp_path / "missing.fbx")
+    # forged sizes: an array record that claims 2^32 - 1 elements in a handful of stored bytes must be rejected
+    # BEFORE anything is allocated, and a child record may not end beyond its parent
+    import struct
+    hdr = b"Kaydara FBX Binary  \x00\x1a\x00" + struct.pack("<I", 7400)
+    def rec(name, props, children=b"", end_delta=0):
+        body = bytes([len(name)]) + name + props + children
+        # end offset is absolute: patched by the caller through `at`
+        return body, end_delta
+    def node(at, name, nprops, props, children=b"", end_delta=0):
+        n = 12 + 1 + len(name) + len(props) + len(children)
+        return struct.pack("<III", at + n + end_delta, nprops, len(props)) + bytes([len(name)]) + name + props + children
+    arr = b"d" + struct.pack("<III", 0xFFFFFFFF, 0, 16) + b"\0" * 16              # 4 G doubles "stored" in 16 raw bytes
+    (tmp_path / "c.fbx").write_bytes(hdr + node(27, b"Objects", 1, arr) + b"\0" * 13)
+    with pytest.raises(ValueError, match="array size inconsistent"):
+        pkg.host_scene.read_fbx(tmp_path / "c.fbx")
+    arr = b"d" + struct.pack("<III", 0x0FFFFFFF, 1, 16) + b"\0" * 16              # 2 GiB claimed from a 16-byte deflate stream
+    (tmp_path / "d.fbx").write_bytes(hdr + node(27, b"Objects", 1, arr) + b"\0" * 13)
+    with pytest.raises(ValueError, match="array size inconsistent"):
+        pkg.host_scene.read_fbx(tmp_path / "d.fbx")
+    child = node(27 + 12 + 1 + 7, b"Geometry", 0, b"", end_delta=40)            # child ends 40 bytes past its parent
+    (tmp_path / "e.fbx").write_bytes(hdr + node(27, b"Objects", 0, b"", child) + b"\0" * 64)
+    with pytest.raises(ValueError, match="bad record end offset"):
+        pkg.host_scene.read_fbx(tmp_path / "e.fbx")
 
 
 def test_fbx_reader_on_the_reference_asset(pkg):
@@ -204,3 +227,14 @@ def test_c3_scene_files_load(pkg):
     P = lambda s: np.stack([s.xs[:, :3], s.ys[:, :3], s.zs[:, :3]], -1).reshape(-1, 3) - c
     assert np.allclose(P(lit), 100 * P(met), rtol=1e-5, atol=1e-4)
     assert abs(np.linalg.norm(P(met), axis=1).max() - 1.0) < 1e-5
+
+
+def test_reference_scene_example_loads_unmodified(pkg):
+    """The reference's scenes/scene_example.json, byte for byte (tests/golden/c3/ holds it next to the veranda map it
+    names): a unit cube (12 triangles) with a GGX dielectric, the spot light placed by the world, the env map."""
+    s = pkg.host_scene.load_json(GOLDEN / "c3" / "scene_example.json")
+    assert s.tri_count == 12 and (s.width, s.height, s.spp, s.max_depth) == (256, 256, 32, 12)
+    assert s.lights.shape == (1, 32) and s.env_rgb.shape == (512, 1024, 3) and s.bsdfs.shape == (1, 32)
+    P = np.stack([s.xs[:, :3], s.ys[:, :3], s.zs[:, :3]], -1).reshape(-1, 3)
+    assert np.allclose(P.min(0), [-0.5, 1.5, -1.5]) and np.allclose(P.max(0), [0.5, 2.5, -0.5])
+
