@@ -52,7 +52,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "dmt_ctx_create", "dmt_ctx_destroy", "dmt_last_error", "dmt_upload_triangles", "dmt_upload_bsdfs",
     "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_bvh_strategy", "dmt_set_partition", "dmt_set_chunk", "dmt_render_profile",
-    "dmt_upload_area_lights", "dmt_upload_envmap", "dmt_clear_envmap", "dmt_envmap_tables", "dmt_test_envmap",
+    "dmt_upload_area_lights", "dmt_upload_textures", "dmt_upload_envmap", "dmt_clear_envmap", "dmt_envmap_tables", "dmt_test_envmap",
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
     "dmt_render", "dmt_render_stats", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
     "dmt_test_sampler", "dmt_test_camera_rays", "dmt_test_bsdf", "dmt_test_light", "dmt_test_half",
@@ -171,6 +171,23 @@ class Renderer:
             self.upload_envmap(scene.env_rgb, scene.env_quat, scene.env_scale)
         else:
             self.clear_envmap()
+        if getattr(scene, "tex_desc", None) is not None and len(scene.tex_desc):
+            self.upload_textures(scene.tex_rgba, scene.tex_desc, scene.mat_tex, scene.tri_uv)
+        else:
+            self.upload_textures(None, None, None, None)
+
+    def upload_textures(self, tex_rgba, tex_desc, mat_tex, tri_uv):
+        """SURVEY 8f-1 image textures (layout: include/dmt_hip.h dmt_upload_textures); all None clears."""
+        if tex_desc is None or len(tex_desc) == 0:
+            self._check(self._lib.dmt_upload_textures(self._ctx, None, C.c_uint64(0), None, C.c_uint32(0), None, C.c_uint32(0), None,
+                                                      C.c_uint64(0)), "dmt_upload_textures")
+            return
+        rgba = np.ascontiguousarray(tex_rgba, np.uint8).reshape(-1, 4)
+        desc = np.ascontiguousarray(tex_desc, np.int32).reshape(-1, 3)
+        mt = np.ascontiguousarray(mat_tex, np.uint32).reshape(-1, 4)
+        uv = np.ascontiguousarray(tri_uv, np.float32).reshape(-1, 6)
+        self._check(self._lib.dmt_upload_textures(self._ctx, _p(rgba), C.c_uint64(rgba.shape[0]), _p(desc), C.c_uint32(desc.shape[0]), _p(mt),
+                                                  C.c_uint32(mt.shape[0]), _p(uv), C.c_uint64(uv.shape[0])), "dmt_upload_textures")
 
     def upload_area_lights(self, tri, le):
         tri = np.ascontiguousarray(tri, np.uint32).reshape(-1)

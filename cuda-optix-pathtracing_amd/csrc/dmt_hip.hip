@@ -62,6 +62,11 @@ struct RenderParams {
   uint32_t const* areaTri;    // [areaCount] ORIGINAL triangle index
   float const* areaLe;        // [areaCount] rgb radiance
   uint32_t areaCount;
+  // SURVEY 8f-1 image textures; read by the *_tex kernels only (layout: dmt_upload_textures)
+  uint32_t const* texRgba;    // RGBA8 texels of every texture, back to back
+  int32_t const* texDesc;     // [texture] {first texel, width, height}
+  uint32_t const* matTex;     // [bsdf] {diffuse, roughness, normal texture or 0xFFFFFFFF, anisotropy as float bits}
+  float const* triUv;         // [triangle] {u0, v0, u1, v1, u2, v2}
   unsigned long long* stats;  // stats build only: samples, closest rays, shadow rays, node visits, triangle tests, bounces
 };
 
@@ -215,7 +220,83 @@ DMT_DEV float area_pdf(TriPost const& P, f3 rayD, float t) {
   return (t * t) / (cosL * (0.5f * len));
 }
 
-template <bool ENV = false, bool AREA = false>
+// ---- image textures of JSON materials.  The reference's megakernel path has none; semantics follow its CPU
+// renderer (src/core/private/core-material.cpp:20-56,180-240; core-texture.cu:895-915): bilinear lookup at MIP level 0
+// (this path carries no ray differentials, and the reference's isotropic fallback picks level 0 when its differentials
+// vanish), mirror wrap, byte / 255, normal maps through Frame::fromZ(ng) after 10-bit quantisation.  The sampled albedo
+// / roughness PATCH the packed record exactly as the host packers would have built it (makeOrenNayar, ggxCommon), so a
+// textured and an untextured material take the same route through bsdf_prepare.
+DMT_DEV f3 tex_texel(uint32_t const* rgba, int32_t first, int32_t w, int32_t h, int s, int t) {
+  auto mirror = [](int c, int size) {
+    int const p = size * 2;
+    c %= p;
+    if (c < 0) c += p;
+    return c < size ? c : (p - c - 1);
+  };
+  uint32_t const px = rgba[size_t(first) + size_t(mirror(t, h)) * size_t(w) + size_t(mirror(s, w))];
+  return mk3(float(px & 0xFFu) / 255.f, float((px >> 8) & 0xFFu) / 255.f, float((px >> 16) & 0xFFu) / 255.f);
+}
+DMT_DEV f3 tex_bilinear(KArgs k, int32_t tex, float s, float t, bool isNormal) {
+  KArgs const ka = kargs(k);
+  int32_t const* const d = ka->texDesc + 3 * tex;
+  int32_t const first = d[0], w = d[1], h = d[2];
+  uint32_t const* const rgba = ka->texRgba;
+  float const x = s * float(w) - 0.5f, y = t * float(h) - 0.5f;
+  float const fx = floorf(x), fy = floorf(y);
+  int const x0 = int(fx), y0 = int(fy);
+  float const tx = x - fx, ty = y - fy;
+  f3 const c00 = tex_texel(rgba, first, w, h, x0, y0), c10 = tex_texel(rgba, first, w, h, x0 + 1, y0);
+  f3 const c01 = tex_texel(rgba, first, w, h, x0, y0 + 1), c11 = tex_texel(rgba, first, w, h, x0 + 1, y0 + 1);
+  f3 const cx0 = c00 * (1.f - tx) + c10 * tx, cx1 = c01 * (1.f - tx) + c11 * tx;
+  f3 c = cx0 * (1.f - ty) + cx1 * ty;
+  if (isNormal) c.x = c.x * 2.f - 1.f, c.y = c.y * 2.f - 1.f;
+  return c;
+}
+// patches `rec` from the material's textures at the hit and returns the shading normal (ng when there is no normal map)
+DMT_DEV f3 apply_material_textures(KArgs k, Rec32& rec, uint32_t matId, int tri, float bu, float bv, f3 ng) {
+  KArgs const ka = kargs(k);
+  uint32_t const* const m = ka->matTex + 4 * matId;
+  int32_t const texD = int32_t(m[0]), texR = int32_t(m[1]), texN = int32_t(m[2]);
+  if (texD < 0 && texR < 0 && texN < 0) return ng;
+  float const aniso = __uint_as_float(m[3]);
+  float const* const uv = ka->triUv + 6 * size_t(tri);
+  float const w0 = 1.f - bu - bv;
+  float const s = w0 * uv[0] + bu * uv[2] + bv * uv[4], t = w0 * uv[1] + bu * uv[3] + bv * uv[5];
+  uint32_t const type = hi16(rec.w[1]);
+  if (texD >= 0 && type == BS_OREN) {
+    f3 const c = tex_bilinear(k, texD, s, t, false);
+    rec.w[0] = f2h(fmaxf(0.f, fminf(c.x, 1.f))) | (f2h(fmaxf(0.f, fminf(c.y, 1.f))) << 16);
+    rec.w[1] = (rec.w[1] & 0xFFFF0000u) | f2h(fmaxf(0.f, fminf(c.z, 1.f)));
+  }
+  if (texR >= 0) {
+    float const rough = fmaxf(0.f, fminf(tex_bilinear(k, texR, s, t, false).x, 1.f));
+    if (type == BS_OREN) {  // makeOrenNayar, CC/private/bsdf.cu:817-844: terms derived from the STORED halves
+      float const kk = (kPi / 2.f) - 2.f / 3.f;
+      uint32_t const hr = f2h(fmaxf(0.f, fminf(rough, kPi / 2.f)));
+      float const sigma = h2f(hr);
+      uint32_t const ha = f2h(1.f / (kPi + kk * sigma));
+      uint32_t const hb = f2h(h2f(ha) * sigma);
+      rec.w[5] = hr | (ha << 16);
+      rec.w[6] = (rec.w[6] & 0xFFFF0000u) | hb;
+    } else if (type == BS_GGX_DIEL || type == BS_GGX_COND) {  // ggxCommon: alpha_y = roughness, alpha_x = anisotropy * roughness
+      float const top = 65535.f;
+      uint32_t const ax = uint32_t(fminf(fmaxf(aniso * rough * top, 0.f), top)), ay = uint32_t(fminf(fmaxf(rough * top, 0.f), top));
+      rec.w[3] = (rec.w[3] & 0x0000FFFFu) | (ax << 16);
+      rec.w[4] = (rec.w[4] & 0xFFFF0000u) | ay;
+    }
+  }
+  if (texN < 0) return ng;
+  f3 n = tex_bilinear(k, texN, s, t, true);
+  auto quant = [](float v) { return float(int(v * 1023.f + 0.5f)) / 1023.f; };
+  n = normalize(mk3(quant(n.x), quant(n.y), quant(n.z)));
+  f3 tx, ty;
+  gram_schmidt(ng, tx, ty);
+  f3 const ns = tx * n.x + ty * n.y + ng * n.z;
+  float const l2 = dot(ns, ns);
+  return (l2 > 0.f && l2 < kInf) ? ns / sqrtf(l2) : ng;
+}
+
+template <bool ENV = false, bool AREA = false, bool TEX = false>
 DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv) {
   SceneView const sc = load_scene(k);
   int const maxDepth = kargs(k)->maxDepth;
@@ -264,7 +345,10 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
   if (st.depth >= maxDepth) return true;  // :154-158
 
   f3 const wo = -rd;
-  Bsdf const b = bsdf_prepare(sc.bsdfs[hit.matId], hit.normal, wo);  // :165-166
+  Rec32 rec = sc.bsdfs[hit.matId];
+  f3 ns = hit.normal;  // shading normal: the geometric one unless a normal map says otherwise
+  if constexpr (TEX) ns = apply_material_textures(k, rec, hit.matId, bestTri, bu, bv, hit.normal);
+  Bsdf const b = bsdf_prepare(rec, ns, wo);  // :165-166
 
   // next-event estimation (:170-241)
   float uLight = st.rng.get1D();
@@ -278,7 +362,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
       EnvSampleDev const es = env_sample(env, uLight2);
       if (es.ok) {
         float bsdfPdf = 0.f;
-        f3 const f = eval_bsdf(b, wo, es.wi, hit.normal, hit.normal, bsdfPdf) * b.weight;
+        f3 const f = eval_bsdf(b, wo, es.wi, ns, hit.normal, bsdfPdf) * b.weight;
         f3 const Le = env_eval_uv(env, es.uv);
         if (!is_zero(f) && max3(Le) > 0.f) {  // core-render.cpp:357-369: Le f / (pdfLight pmf + pdfBsdf), pmf = 1/2
           put_C(st.beta * (Le * f / (es.pdf * 0.5f + bsdfPdf)));
@@ -299,7 +383,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
       AreaSampleDev const as = area_sample(sc.post[ka->areaTri[ai]], hit.pos, uLight2);
       if (as.ok) {
         float bsdfPdf = 0.f;
-        f3 const f = eval_bsdf(b, wo, as.wi, hit.normal, hit.normal, bsdfPdf) * b.weight;
+        f3 const f = eval_bsdf(b, wo, as.wi, ns, hit.normal, bsdfPdf) * b.weight;
         if (!is_zero(f)) {
           f3 const Le = mk3(ka->areaLe[3 * ai], ka->areaLe[3 * ai + 1], ka->areaLe[3 * ai + 2]);
           float const a = as.pdf * (ENV ? 0.5f : 1.f) / float(nAll), bb = bsdfPdf;
@@ -318,7 +402,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
     LightSample const ls = sample_light(light, hit.pos, uLight2, st.lastT, hit.normal);
     if (ls.valid()) {
       float bsdfPdf = 0.f;
-      f3 const f = eval_bsdf(b, wo, ls.direction, hit.normal, hit.normal, bsdfPdf) * b.weight;
+      f3 const f = eval_bsdf(b, wo, ls.direction, ns, hit.normal, bsdfPdf) * b.weight;
       if (!is_zero(f)) {
         f3 const Le = eval_light(light, ls);
         if (ls.delta) {
@@ -338,7 +422,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
   // bounce (:247-295); get2D before get1D = left-to-right argument evaluation
   f2 const u2 = st.rng.get2D();
   float const uc = st.rng.get1D();
-  BsdfSample const bs = sample_bsdf(b, wo, hit.normal, hit.normal, u2, uc);
+  BsdfSample const bs = sample_bsdf(b, wo, ns, hit.normal, u2, uc);
   if (!bs.valid()) return true;
   st.lastT = bs.refract;
   if constexpr (ENV || AREA) st.lastPdf = bs.pdf, st.lastSpecular = bs.delta;
@@ -439,11 +523,11 @@ DMT_DEV void trace_pair_bvh(KArgs k, PathState const& st, bool doC, bool doS, ui
 
 // One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
 // sink(L, sidx) is called once per completed sample with the index the sample was started with.
-template <bool ENV = false, bool AREA = false, class Sink>
+template <bool ENV = false, bool AREA = false, bool TEX = false, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink);
 
-template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, class Sink>
+template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false, class Sink>
 DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneStats* ls = nullptr) {
   bool const doC = st.active;
   bool const doS = st.hasShadow;
@@ -455,11 +539,11 @@ DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneS
   else
     trace_pair_brute(k, st, doC, doS, bestTri, bu, bv, occluded);
   if constexpr (STATS) ls->bounces += (doC && bestTri >= 0 && st.depth < kargs(k)->maxDepth) ? 1u : 0u;
-  lane_finish<ENV, AREA>(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
+  lane_finish<ENV, AREA, TEX>(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
 }
 
 // Second half of a ray pass: resolve the shadow ray (in the reference's accumulation order), then shade.
-template <bool ENV, bool AREA, class Sink>
+template <bool ENV, bool AREA, bool TEX, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink) {
   if (doS) {
@@ -474,7 +558,7 @@ DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri
     }
   }
   if (doC) {
-    if (path_shade<ENV, AREA>(k, st, bestTri, bu, bv)) {
+    if (path_shade<ENV, AREA, TEX>(k, st, bestTri, bu, bv)) {
       st.active = false;
       if (st.hasShadow) {  // last NEE still untraced: park the sample, the lane may start the next
         put_Lfin(st.L);
@@ -821,7 +905,7 @@ DMT_DEV void flush_stats(KArgs Pk, LaneStats const& ls) {
   }
 }
 
-template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false>
+template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false>
 DMT_DEV void megakernel_body() {
   KArgs const Pk = kargs_base();
   LaneStats ls;
@@ -852,7 +936,7 @@ DMT_DEV void megakernel_body() {
           }
         }
       }
-      lane_step<BVH, STATS, ENV, AREA>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
+      lane_step<BVH, STATS, ENV, AREA, TEX>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
     }
   }
   flush_stats<STATS>(Pk, ls);
@@ -874,7 +958,7 @@ DMT_DEV void megakernel_body() {
 #ifndef DMT_BVH_DUMMY_LDS
 #define DMT_BVH_DUMMY_LDS 0  // occupancy experiments: extra LDS bytes per block (fewer resident blocks per CU)
 #endif
-template <bool STATS = false, bool ENV = false, bool AREA = false>
+template <bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false>
 DMT_DEV void megakernel_body_bvh() {
   KArgs const Pk = kargs_base();
 #if DMT_BVH_DUMMY_LDS > 0
@@ -978,7 +1062,7 @@ DMT_DEV void megakernel_body_bvh() {
       if constexpr (STATS) ++ls.itShade, ls.lanesShade += tv.phase == TR_DONE ? 1u : 0u;
       if (tv.phase == TR_DONE) {
         if constexpr (STATS) ls.bounces += (tv.doC && tv.bestTri >= 0 && st.depth < kargs(Pk)->maxDepth) ? 1u : 0u;
-        lane_finish<ENV, AREA>(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
+        lane_finish<ENV, AREA, TEX>(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
         tv.phase = TR_IDLE;
       }
     }
@@ -1001,6 +1085,11 @@ __global__ void __launch_bounds__(256, 2) k_megakernel_bvh_stats_env(RenderParam
 // emissive triangles compiled in (dmt_upload_area_lights selects them)
 __global__ void __launch_bounds__(256, 4) k_megakernel_area(RenderParams P) { megakernel_body<false, false, false, true>(); }
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_area(RenderParams P) { megakernel_body_bvh<false, false, true>(); }
+// image textures compiled in (dmt_upload_textures selects them); with or without the env map
+__global__ void __launch_bounds__(256, 4) k_megakernel_tex(RenderParams P) { megakernel_body<false, false, false, false, true>(); }
+__global__ void __launch_bounds__(256, 3) k_megakernel_bvh_tex(RenderParams P) { megakernel_body_bvh<false, false, false, true>(); }
+__global__ void __launch_bounds__(256, 4) k_megakernel_env_tex(RenderParams P) { megakernel_body<false, false, true, false, true>(); }
+__global__ void __launch_bounds__(256, 3) k_megakernel_bvh_env_tex(RenderParams P) { megakernel_body_bvh<false, true, false, true>(); }
 // both optional light kinds at once
 __global__ void __launch_bounds__(256, 4) k_megakernel_env_area(RenderParams P) { megakernel_body<false, false, true, true>(); }
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_env_area(RenderParams P) { megakernel_body_bvh<false, true, true>(); }
@@ -1024,7 +1113,18 @@ __global__ void k_test_trace(RenderParams P, bool useBvh, int n, int32_t const* 
   for (;;) {
     if (!__any(st.active || st.hasShadow)) break;
     bool const useEnv = kargs(k)->env.w > 0;
-    if (kargs(k)->areaCount > 0 && useEnv) {
+    if (kargs(k)->matTex != nullptr) {
+      if (useEnv) {
+        if (useBvh)
+          lane_step<true, false, true, false, true>(k, gtid, st, store);
+        else
+          lane_step<false, false, true, false, true>(k, gtid, st, store);
+      } else if (useBvh) {
+        lane_step<true, false, false, false, true>(k, gtid, st, store);
+      } else {
+        lane_step<false, false, false, false, true>(k, gtid, st, store);
+      }
+    } else if (kargs(k)->areaCount > 0 && useEnv) {
       if (useBvh)
         lane_step<true, false, true, true>(k, gtid, st, store);
       else
@@ -1254,6 +1354,14 @@ struct dmt_ctx {
   int bvhDepth = 0;
   uint32_t bvhNodeCount = 0, bvhPairCount = 0;
   int blocksPerCUBvh = 0;
+  std::vector<std::pair<void const*, int>> occupancy;  // megakernel variant -> resident 256-thread blocks per CU
+  // SURVEY 8f-1 image textures (one allocation each)
+  uint32_t* d_texRgba = nullptr;
+  int32_t* d_texDesc = nullptr;
+  uint32_t* d_matTex = nullptr;
+  float* d_triUv = nullptr;
+  uint32_t texCount = 0, matTexCount = 0;
+  size_t triUvCount = 0;
   // wavefront form of the BVH path (wavefront.hpp)
   int bvhStrategy = 0;             // 0 = automatic (by launch size), 1 = megakernel, 2 = wavefront
   size_t wfTargetPaths = size_t(1) << 22;  // path slots per pass
@@ -1262,10 +1370,8 @@ struct dmt_ctx {
   uint32_t* d_wfCounts = nullptr;  // counts + cursors
   size_t wfSlotsCap = 0, wfCountsCap = 0;
   int wfBlocksTrace = 0, wfBlocksShade = 0;
-  int blocksPerCUEnv = 0, blocksPerCUBvhEnv = 0;
   float* d_env = nullptr;  // A18: one allocation holding the five tables and the image
   EnvView env{};           // env.w == 0: no env map
-  int blocksPerCUArea = 0, blocksPerCUBvhArea = 0;
   uint32_t* d_areaOf = nullptr;   // per-triangle area-light index
   uint32_t* d_areaTri = nullptr;
   float* d_areaLe = nullptr;
@@ -1404,14 +1510,28 @@ RenderParams baseParams(dmt_ctx const* c, size_t threads) {
   P.maxDepth = c->maxDepth;
   P.env = c->env;
   P.areaOf = c->d_areaOf, P.areaTri = c->d_areaTri, P.areaLe = c->d_areaLe, P.areaCount = c->areaCount;
+  if (c->texCount > 0) P.texRgba = c->d_texRgba, P.texDesc = c->d_texDesc, P.matTex = c->d_matTex, P.triUv = c->d_triUv;
   return P;
 }
 
-int blocksPerCuOf(dmt_ctx const* c) {
-  bool const env = c->env.w > 0;
-  if (c->areaCount > 0) return c->accel == DMT_ACCEL_BVH ? c->blocksPerCUBvhArea : c->blocksPerCUArea;
-  if (c->accel == DMT_ACCEL_BVH) return env ? c->blocksPerCUBvhEnv : c->blocksPerCUBvh;
-  return env ? c->blocksPerCUEnv : c->blocksPerCU;
+// which megakernel a launch of this context runs: accelerator x optional light kinds x textures
+typedef void (*MegakernelFn)(RenderParams);
+MegakernelFn megakernelOf(dmt_ctx const* c) {
+  bool const bvh = c->accel == DMT_ACCEL_BVH, env = c->env.w > 0, area = c->areaCount > 0, tex = c->texCount > 0;
+  if (tex) return bvh ? (env ? k_megakernel_bvh_env_tex : k_megakernel_bvh_tex) : (env ? k_megakernel_env_tex : k_megakernel_tex);
+  if (area && env) return bvh ? k_megakernel_bvh_env_area : k_megakernel_env_area;
+  if (area) return bvh ? k_megakernel_bvh_area : k_megakernel_area;
+  if (env) return bvh ? k_megakernel_bvh_env : k_megakernel_env;
+  return bvh ? k_megakernel_bvh : k_megakernel;
+}
+int blocksPerCuOf(dmt_ctx* c) {
+  void const* const fn = reinterpret_cast<void const*>(megakernelOf(c));
+  for (auto const& e : c->occupancy)
+    if (e.first == fn) return e.second;
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, 0) != hipSuccess || n <= 0) n = 1;
+  c->occupancy.emplace_back(fn, n);
+  return n;
 }
 
 template <class T>
@@ -1540,11 +1660,6 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
   int bpcBvh = 0;
   if (e == hipSuccess)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpcBvh, reinterpret_cast<void const*>(k_megakernel_bvh), 256, 0);
-  int bpcEnv = 0, bpcBvhEnv = 0;
-  if (e == hipSuccess)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpcEnv, reinterpret_cast<void const*>(k_megakernel_env), 256, 0);
-  if (e == hipSuccess)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpcBvhEnv, reinterpret_cast<void const*>(k_megakernel_bvh_env), 256, 0);
   if (e != hipSuccess) {
     g_createError = std::string("dmt_ctx_create: ") + hipGetErrorString(e);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -1555,14 +1670,6 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
   ctx->cuCount = prop.multiProcessorCount;
   ctx->blocksPerCU = bpc > 0 ? bpc : 1;
   ctx->blocksPerCUBvh = bpcBvh > 0 ? bpcBvh : 1;
-  ctx->blocksPerCUEnv = bpcEnv > 0 ? bpcEnv : 1;
-  ctx->blocksPerCUBvhEnv = bpcBvhEnv > 0 ? bpcBvhEnv : 1;
-  {
-    int a = 0, b = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<void const*>(k_megakernel_area), 256, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<void const*>(k_megakernel_bvh_area), 256, 0);
-    ctx->blocksPerCUArea = a > 0 ? a : 1, ctx->blocksPerCUBvhArea = b > 0 ? b : 1;
-  }
   if (char const* e3 = std::getenv("DMT_BVH_STRATEGY")) {  // experiments: 0 auto, 1 megakernel, 2 wavefront
     int const v = std::atoi(e3);
     ctx->bvhStrategy = v < 0 || v > 2 ? 0 : v;
@@ -1602,6 +1709,10 @@ int dmt_ctx_destroy(dmt_ctx* ctx) {
   (void)hipFree(ctx->d_bvhNodes);
   (void)hipFree(ctx->d_trisBvh);
   (void)hipFree(ctx->d_overflow);
+  (void)hipFree(ctx->d_texRgba);
+  (void)hipFree(ctx->d_texDesc);
+  (void)hipFree(ctx->d_matTex);
+  (void)hipFree(ctx->d_triUv);
   (void)hipFree(ctx->d_wfState);
   (void)hipFree(ctx->d_wfQueue);
   (void)hipFree(ctx->d_wfCounts);
@@ -1950,7 +2061,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   uint32_t const ownedTiles = P.numItems;
   // BVH launches run as the megakernel unless the wavefront form (wavefront.hpp) is asked for: on the measured scenes
   // the megakernel is faster (1 M triangles: 489 vs 378 Msamples/s), so "automatic" means megakernel
-  bool const wavefront = ctx->accel == DMT_ACCEL_BVH && ctx->bvhStrategy == 2;
+  bool const wavefront = ctx->accel == DMT_ACCEL_BVH && ctx->bvhStrategy == 2 && ctx->texCount == 0;  // textures: megakernels only
   {  // fewer owned tiles than ~4 per resident wave: schedule row bands of the tiles instead of whole tiles
     uint32_t const waves = uint32_t(ctx->cuCount) * uint32_t(blocksPerCuOf(ctx)) * 4u;
     P.subShift = ctx->subShift >= 0 ? uint32_t(ctx->subShift) : 0u;
@@ -1982,6 +2093,12 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   bool const useArea = ctx->areaCount > 0;
   P.env = ctx->env;
   P.areaOf = ctx->d_areaOf, P.areaTri = ctx->d_areaTri, P.areaLe = ctx->d_areaLe, P.areaCount = ctx->areaCount;
+  if (ctx->texCount > 0) {
+    if (useArea) return fail(ctx, DMT_ERR_STATE, "dmt_render: image textures together with emissive triangles are not supported");
+    if (ctx->matTexCount != ctx->bsdfCount || ctx->triUvCount != ctx->triCount)
+      return fail(ctx, DMT_ERR_STATE, "dmt_render: texture tables do not match the uploaded BSDFs / triangles (upload textures last)");
+    P.texRgba = ctx->d_texRgba, P.texDesc = ctx->d_texDesc, P.matTex = ctx->d_matTex, P.triUv = ctx->d_triUv;
+  }
   uint32_t const blocksNeeded = (wavesWanted + 3) / 4;
   if (blocks > blocksNeeded) blocks = blocksNeeded;
   if (blocks == 0) blocks = 1;
@@ -2013,7 +2130,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
     if (stats6) return DMT_OK;
   } else if (useBvh) {
     if (!ctx->haveBvh) return fail(ctx, DMT_ERR_STATE, "dmt_render: BVH not built");
-    int const rcO = ensureOverflow(ctx, size_t(ctx->cuCount) * size_t(blocksPerCuOf(ctx) > ctx->blocksPerCUBvh ? blocksPerCuOf(ctx) : ctx->blocksPerCUBvh) * 256);
+    int const rcO = ensureOverflow(ctx, size_t(ctx->cuCount) * size_t(std::max(blocksPerCuOf(ctx), ctx->blocksPerCUBvh)) * 256);
     if (rcO) return rcO;
     P.bvh = bvhView(ctx, size_t(blocks) * 256);
     if (stats6) {
@@ -2032,22 +2149,9 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
       HIP_TRY(ctx, e);
       return DMT_OK;
     }
-    if (useArea && useEnv)
-      hipLaunchKernelGGL(k_megakernel_bvh_env_area, dim3(blocks), dim3(256), 0, ctx->stream, P);
-    else if (useArea)
-      hipLaunchKernelGGL(k_megakernel_bvh_area, dim3(blocks), dim3(256), 0, ctx->stream, P);
-    else if (useEnv)
-      hipLaunchKernelGGL(k_megakernel_bvh_env, dim3(blocks), dim3(256), 0, ctx->stream, P);
-    else
-      hipLaunchKernelGGL(k_megakernel_bvh, dim3(blocks), dim3(256), 0, ctx->stream, P);
-  } else if (useArea && useEnv) {
-    hipLaunchKernelGGL(k_megakernel_env_area, dim3(blocks), dim3(256), 0, ctx->stream, P);
-  } else if (useArea) {
-    hipLaunchKernelGGL(k_megakernel_area, dim3(blocks), dim3(256), 0, ctx->stream, P);
-  } else if (useEnv) {
-    hipLaunchKernelGGL(k_megakernel_env, dim3(blocks), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(megakernelOf(ctx), dim3(blocks), dim3(256), 0, ctx->stream, P);
   } else {
-    hipLaunchKernelGGL(k_megakernel, dim3(blocks), dim3(256), 0, ctx->stream, P);
+    hipLaunchKernelGGL(megakernelOf(ctx), dim3(blocks), dim3(256), 0, ctx->stream, P);
   }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
@@ -2170,6 +2274,39 @@ int dmt_upload_area_lights(dmt_ctx* ctx, const uint32_t* triangle_index, const f
   ctx->h_areaTri.assign(triangle_index, triangle_index + count);
   ctx->h_areaLe.assign(radiance_rgb, radiance_rgb + 3 * size_t(count));
   return rebuildAreaLights(ctx);
+}
+
+int dmt_upload_textures(dmt_ctx* ctx, const uint8_t* rgba8, uint64_t texel_count, const int32_t* desc3, uint32_t texture_count,
+                        const uint32_t* mat_tex4, uint32_t bsdf_count, const float* tri_uv6, uint64_t triangle_count) {
+  if (!ctx) return DMT_ERR_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(ctx->d_texRgba), (void)hipFree(ctx->d_texDesc), (void)hipFree(ctx->d_matTex), (void)hipFree(ctx->d_triUv);
+  ctx->d_texRgba = nullptr, ctx->d_texDesc = nullptr, ctx->d_matTex = nullptr, ctx->d_triUv = nullptr;
+  ctx->texCount = 0, ctx->matTexCount = 0, ctx->triUvCount = 0;
+  if (texture_count == 0) return DMT_OK;  // cleared
+  if (!rgba8 || !desc3 || !mat_tex4 || !tri_uv6 || texel_count == 0 || bsdf_count == 0 || triangle_count == 0)
+    return fail(ctx, DMT_ERR_INVALID, "dmt_upload_textures: null array or zero count");
+  for (uint32_t k = 0; k < texture_count; ++k) {  // descriptors must stay inside the texel array
+    int64_t const first = desc3[3 * k], w = desc3[3 * k + 1], h = desc3[3 * k + 2];
+    if (first < 0 || w <= 0 || h <= 0 || uint64_t(first) + uint64_t(w) * uint64_t(h) > texel_count)
+      return fail(ctx, DMT_ERR_INVALID, "dmt_upload_textures: texture descriptor outside the texel array");
+  }
+  for (uint32_t b = 0; b < bsdf_count; ++b)
+    for (int j = 0; j < 3; ++j) {
+      uint32_t const t = mat_tex4[4 * size_t(b) + size_t(j)];
+      if (t != 0xFFFFFFFFu && t >= texture_count) return fail(ctx, DMT_ERR_INVALID, "dmt_upload_textures: material refers to a texture that does not exist");
+    }
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_texRgba), size_t(texel_count) * 4));
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_texDesc), size_t(texture_count) * 12));
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_matTex), size_t(bsdf_count) * 16));
+  HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_triUv), size_t(triangle_count) * 24));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_texRgba, rgba8, size_t(texel_count) * 4, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_texDesc, desc3, size_t(texture_count) * 12, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_matTex, mat_tex4, size_t(bsdf_count) * 16, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_triUv, tri_uv6, size_t(triangle_count) * 24, hipMemcpyHostToDevice));
+  ctx->texCount = texture_count, ctx->matTexCount = bsdf_count, ctx->triUvCount = size_t(triangle_count);
+  return DMT_OK;
 }
 
 int dmt_envmap_tables(const float* rgb, int width, int height, float* func, float* cdf, float* row_integral,

@@ -112,6 +112,16 @@ int dmt_upload_area_lights(dmt_ctx* ctx, const uint32_t* triangle_index, const f
  * `scale` is accepted for signature parity; the reference stores it and never applies it. */
 int dmt_upload_envmap(dmt_ctx* ctx, const float* rgb, int width, int height, const float* quat_xyzw, float scale);
 int dmt_clear_envmap(dmt_ctx* ctx);
+/* SURVEY 8f-1 -- image textures of JSON materials ("textures" + string-valued "diffuse" / "roughness" / "normal" of
+ * src/core/private/core-parser.cpp:306-560; the reference's megakernel has none, semantics are its CPU renderer's,
+ * src/core/private/core-material.cpp:20-56,180-240): bilinear at MIP level 0, mirror wrap, byte / 255; the sampled albedo
+ * and roughness patch the material's packed record as the host packers would build it, a normal map turns the geometric
+ * normal into the shading normal.  rgba8: texel_count RGBA8 texels, all textures back to back, row major;
+ * desc3[texture] = {first texel, width, height}; mat_tex4[bsdf] = {diffuse, roughness, normal texture index or
+ * 0xFFFFFFFF, anisotropy as float bits}; tri_uv6[triangle] = {u0, v0, u1, v1, u2, v2}.  Upload AFTER triangles and
+ * BSDFs (the counts must match at render time); texture_count == 0 clears.  Not combinable with emissive triangles. */
+int dmt_upload_textures(dmt_ctx* ctx, const uint8_t* rgba8, uint64_t texel_count, const int32_t* desc3, uint32_t texture_count,
+                        const uint32_t* mat_tex4, uint32_t bsdf_count, const float* tri_uv6, uint64_t triangle_count);
 /* host only (no GPU needed): the sampling tables dmt_upload_envmap builds; func/cdf: height*width floats each,
  * row_integral / marginal_func / marginal_cdf: height floats each */
 int dmt_envmap_tables(const float* rgb, int width, int height, float* func, float* cdf, float* row_integral,

@@ -661,6 +661,7 @@ struct Hit {
   int32_t hit = 0;
   uint32_t matId = 0;
   float t = std::numeric_limits<float>::infinity();
+  float u = 0.f, v = 0.f;  // barycentric weights of p1, p2 (texture coordinates of textured materials)
 };
 inline float gammaf(int n) {  // extra_math.cuh:21-29
   float const f = float(n) * std::numeric_limits<float>::epsilon() * 0.5f;
@@ -693,6 +694,7 @@ Hit triangleIntersect(float const* x, float const* y, float const* z, Ray ray) {
     V3 const p2 = v3(x[2], y[2], z[2]);
     r.hit = 1;
     r.t = t;
+    r.u = u, r.v = v;
     r.pos = p0 + u * e0 + v * e1;
     r.normal = normalize(cross(e1, e0));
     r.error = triError(u, v, p0, p1, p2);
@@ -1555,6 +1557,15 @@ struct Scene {
   uint32_t const* areaTri = nullptr;
   float const* areaLe = nullptr;  // rgb per area light
   uint32_t areaCount = 0;
+  // image textures of JSON materials (no implementation on the reference's megakernel path; semantics follow
+  // its CPU renderer, src/core/private/core-material.cpp:20-56,180-240).  texDesc[k] = {first texel, width, height} into
+  // texRgba (RGBA8); matTex[bsdf] = {diffuse, roughness, normal texture index or -1, anisotropy as float bits};
+  // triUv[tri] = {u0, v0, u1, v1, u2, v2}
+  uint8_t const* texRgba = nullptr;
+  int32_t const* texDesc = nullptr;
+  uint32_t texCount = 0;
+  uint32_t const* matTex = nullptr;
+  float const* triUv = nullptr;
 };
 
 struct Stats {  // algorithmic work counters (SURVEY 8d byte model)
@@ -1631,6 +1642,78 @@ inline float areaPdf(Scene const& sc, uint32_t tri, V3 rayD, float t) {
 }
 
 // one path; returns radiance L                                      megakernel.cu:103-297
+// ---- image textures ------------------------------------------------------------------------------
+// One texel: mirror wrap (the only mode the reference's material code asks for, core-material.cpp:114-116), byte / 255
+// (core-texture.cu readRGB of ByteRGB).  core-texture.cu:895-915.
+inline V3 texel(Scene const& sc, int32_t tex, int s, int t) {
+  int32_t const* d = sc.texDesc + 3 * tex;
+  auto mirror = [](int c, int size) {
+    int const p = size * 2;
+    c %= p;
+    if (c < 0) c += p;
+    return c < size ? c : (p - c - 1);
+  };
+  uint8_t const* px = sc.texRgba + 4 * (size_t(d[0]) + size_t(mirror(t, d[2])) * size_t(d[1]) + size_t(mirror(s, d[1])));
+  return v3(float(px[0]) / 255.f, float(px[1]) / 255.f, float(px[2]) / 255.f);
+}
+// sampleBilinearTexel at MIP level 0, core-material.cpp:20-56 (the megakernel path carries no ray differentials; the
+// reference's isotropic fallback selects level 0 whenever its differentials are near zero, :104-116)
+inline V3 textureBilinear(Scene const& sc, int32_t tex, float s, float t, bool isNormal) {
+  int32_t const* d = sc.texDesc + 3 * tex;
+  float const x = s * float(d[1]) - 0.5f, y = t * float(d[2]) - 0.5f;
+  int const x0 = int(floorf(x)), y0 = int(floorf(y));
+  float const tx = x - float(x0), ty = y - float(y0);
+  V3 const c00 = texel(sc, tex, x0, y0), c10 = texel(sc, tex, x0 + 1, y0), c01 = texel(sc, tex, x0, y0 + 1),
+           c11 = texel(sc, tex, x0 + 1, y0 + 1);
+  auto lerpc = [](V3 a, V3 b, float w) { return a * (1.f - w) + b * w; };
+  V3 c = lerpc(lerpc(c00, c10, tx), lerpc(c01, c11, tx), ty);
+  if (isNormal) c.x = c.x * 2.f - 1.f, c.y = c.y * 2.f - 1.f;  // z stays as stored (:49-52)
+  return c;
+}
+// Applies the material's textures at a hit: patches the packed record the way the host packers build it
+// (makeOrenNayar / bsdfGGXCommon above) from the sampled albedo / roughness, and returns the shading normal.
+inline V3 applyMaterialTextures(Scene const& sc, Rec32& rec, uint32_t matId, int tri, float bu, float bv, V3 ng) {
+  if (!sc.matTex || !sc.triUv) return ng;
+  uint32_t const* m = sc.matTex + 4 * matId;
+  int32_t const texD = int32_t(m[0]), texR = int32_t(m[1]), texN = int32_t(m[2]);
+  if (texD < 0 && texR < 0 && texN < 0) return ng;
+  float aniso;
+  memcpy(&aniso, &m[3], 4);
+  float const* uv = sc.triUv + 6 * size_t(tri);
+  float const w0 = 1.f - bu - bv;
+  float const s = w0 * uv[0] + bu * uv[2] + bv * uv[4], t = w0 * uv[1] + bu * uv[3] + bv * uv[5];
+  uint16_t const type = bsdfType(rec);
+  if (texD >= 0 && type == BS_OREN) {
+    V3 const c = textureBilinear(sc, texD, s, t, false);
+    wrh3(rec, B_WEIGHT, v3(fmaxf(0, fminf(c.x, 1)), fmaxf(0, fminf(c.y, 1)), fmaxf(0, fminf(c.z, 1))));
+  }
+  if (texR >= 0) {
+    float const rough = fmaxf(0.f, fminf(textureBilinear(sc, texR, s, t, false).x, 1.f));
+    if (type == BS_OREN) {
+      float const k = (kPi / 2.f) - 2.f / 3.f;
+      wr16(rec, ON_ROUGH, f2h(fmaxf(0, fminf(rough, kPi / 2.f))));
+      float const sigma = h2f(rd16(rec, ON_ROUGH));
+      wr16(rec, ON_A, f2h(1.f / (kPi + k * sigma)));
+      float const a = h2f(rd16(rec, ON_A));
+      wr16(rec, ON_B, f2h(a * sigma));
+    } else if (type == BS_GGX_DIEL || type == BS_GGX_COND) {  // alpha_y = roughness, alpha_x = anisotropy * roughness (:262-263)
+      float const U16 = 65535.f;
+      wr16(rec, G_AX, uint16_t(fminf(fmaxf(aniso * rough * U16, 0.f), U16)));
+      wr16(rec, G_AY, uint16_t(fminf(fmaxf(rough * U16, 0.f), U16)));
+    }
+  }
+  if (texN < 0) return ng;
+  // core-material.cpp:188-200: sample, quantise to 10 bits and normalise, rotate out of Frame::fromZ(ng)
+  V3 n = textureBilinear(sc, texN, s, t, true);
+  auto quant = [](float v) { return float(int(v * 1023.f + 0.5f)) / 1023.f; };  // fl::quantize, cudautils-float.cuh:357-361
+  n = normalize(v3(quant(n.x), quant(n.y), quant(n.z)));
+  V3 tx, ty;
+  gramSchmidt(ng, &tx, &ty);
+  V3 const ns = tx * n.x + ty * n.y + ng * n.z;
+  float const l2 = length2(ns);
+  return (l2 > 0.f && std::isfinite(l2)) ? ns / sqrtf(l2) : ng;  // safeNormalizeFallback
+}
+
 struct PathLog {  // optional per-bounce record sink: {tri, pos3, beta3, L3, depth, dim} = 12 floats
   float* rec = nullptr;
   int cap = 0, n = 0;
@@ -1705,7 +1788,8 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
     if (depth >= cfg.maxDepth) break;
     if (st) st->bounces++, st->hits++;
     bsdf = sc.bsdfs[hit.matId];
-    prepareBSDF(&bsdf, hit.normal, -ray.d, transmissionCount);
+    V3 const ns = applyMaterialTextures(sc, bsdf, hit.matId, hitTri, hit.u, hit.v, hit.normal);  // = hit.normal without textures
+    prepareBSDF(&bsdf, ns, -ray.d, transmissionCount);
 
     float uLight = rng.get1D();
     V2 const uLight2 = rng.get2D();
@@ -1740,7 +1824,7 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
         }
         if (visible) {
           float bsdfPdf = 0;
-          V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, hit.normal, hit.normal, &bsdfPdf) * bsdfWeight(bsdf);
+          V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, ns, hit.normal, &bsdfPdf) * bsdfWeight(bsdf);
           if (!isZero(f)) {
             V3 const Le = v3(sc.areaLe[3 * areaIdx], sc.areaLe[3 * areaIdx + 1], sc.areaLe[3 * areaIdx + 2]);
             float const a = as.pdf * listPmfScale / float(sc.lightCount + sc.areaCount), b = bsdfPdf;
@@ -1763,7 +1847,7 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
         }
         if (visible) {
           float bsdfPdf = 0;
-          V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, hit.normal, hit.normal, &bsdfPdf) * bsdfWeight(bsdf);
+          V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, ns, hit.normal, &bsdfPdf) * bsdfWeight(bsdf);
           V3 const Le = envEvalUv(*sc.env, es.uv);
           // core-render.cpp:357-369: Le f / (pdfLight pmf + pdfBsdf), pmf = 1/2
           if (!isZero(f) && maxComponent(Le) > 0.f) L += beta * (Le * f / (es.pdf * 0.5f + bsdfPdf));
@@ -1788,7 +1872,7 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
         }
         if (doNEE) {
           float bsdfPdf = 0;
-          V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, hit.normal, hit.normal, &bsdfPdf) *
+          V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, ns, hit.normal, &bsdfPdf) *
                        bsdfWeight(bsdf);
           V3 const Le = evalLight(light, ls);
           if (!isZero(f)) {
@@ -1811,7 +1895,7 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
       u2 = rng.get2D();
       uc = rng.get1D();
     }
-    BSDFSample const bs = sampleBsdf(bsdf, -ray.d, hit.normal, hit.normal, u2, uc);
+    BSDFSample const bs = sampleBsdf(bsdf, -ray.d, ns, hit.normal, u2, uc);
     if (!bs.valid()) break;
     transmissionCount += bs.refract;
     lastBounceTransmission = bs.refract;
@@ -2007,6 +2091,12 @@ struct OracleScene {  // mirrors include/dmt_hip.h's upload calls
   const uint32_t* areaTri;
   const float* areaLe;
   uint32_t areaCount;
+  // image textures, see Scene
+  const uint8_t* texRgba;
+  const int32_t* texDesc;
+  uint32_t texCount;
+  const uint32_t* matTex;
+  const float* triUv;
 };
 
 static Scene toScene(OracleScene const* s, EnvMap* envStorage = nullptr, std::vector<uint32_t>* areaStorage = nullptr) {
@@ -2025,6 +2115,8 @@ static Scene toScene(OracleScene const* s, EnvMap* envStorage = nullptr, std::ve
   sc.lights = reinterpret_cast<Rec32 const*>(s->lights), sc.lightCount = s->lightCount;
   sc.infLights = reinterpret_cast<Rec32 const*>(s->infLights), sc.infLightCount = s->infLightCount;
   sc.bsdfs = reinterpret_cast<Rec32 const*>(s->bsdfs), sc.bsdfCount = s->bsdfCount;
+  if (s->texCount > 0 && s->texRgba && s->texDesc && s->matTex && s->triUv)
+    sc.texRgba = s->texRgba, sc.texDesc = s->texDesc, sc.texCount = s->texCount, sc.matTex = s->matTex, sc.triUv = s->triUv;
   return sc;
 }
 

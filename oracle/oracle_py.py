@@ -30,6 +30,7 @@ class OracleScene(C.Structure):
         ("envRgb", C.c_void_p), ("envW", C.c_int32), ("envH", C.c_int32), ("envQuat", C.c_float * 4),
         ("envScale", C.c_float),
         ("areaTri", C.c_void_p), ("areaLe", C.c_void_p), ("areaCount", C.c_uint32),
+        ("texRgba", C.c_void_p), ("texDesc", C.c_void_p), ("texCount", C.c_uint32), ("matTex", C.c_void_p), ("triUv", C.c_void_p),
     ]
 
 
@@ -123,7 +124,21 @@ class Scene:
             s.envScale = self.env_scale
         if self.area_tri is not None and self.area_tri.shape[0] > 0:
             s.areaTri, s.areaLe, s.areaCount = _p(self.area_tri), _p(self.area_le), self.area_tri.shape[0]
+        if getattr(self, "tex_desc", None) is not None and len(self.tex_desc) > 0:
+            s.texRgba, s.texDesc, s.texCount = _p(self.tex_rgba), _p(self.tex_desc), self.tex_desc.shape[0]
+            s.matTex, s.triUv = _p(self.mat_tex), _p(self.tri_uv)
         return s
+
+    def set_textures(self, tex_rgba, tex_desc, mat_tex, tri_uv):
+        """RGBA8 texel atlas [T, 4], descriptors int32 [n, 3] = (first texel, width, height), per-BSDF
+        uint32 [nbsdf, 4] = (diffuse, roughness, normal texture or 0xFFFFFFFF, anisotropy float bits), per-triangle
+        float32 [ntri, 6] = (u0, v0, u1, v1, u2, v2)."""
+        self.tex_rgba = np.ascontiguousarray(tex_rgba, np.uint8).reshape(-1, 4)
+        self.tex_desc = np.ascontiguousarray(tex_desc, np.int32).reshape(-1, 3)
+        self.mat_tex = np.ascontiguousarray(mat_tex, np.uint32).reshape(-1, 4)
+        self.tri_uv = np.ascontiguousarray(tri_uv, np.float32).reshape(-1, 6)
+        assert self.mat_tex.shape[0] == self.bsdfs.shape[0] and self.tri_uv.shape[0] == self.tri_count
+        return self
 
 
 def cornell_box(width=None, height=None):

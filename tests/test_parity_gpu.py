@@ -958,3 +958,88 @@ def test_env_map_and_area_lights_together(renderer, pkg, O, accel):
     scale = float(om[..., :3].mean())
     assert scale > 0.2
     assert float(np.sqrt(np.mean((mean[..., :3] - om[..., :3]) ** 2))) < 2e-3 * scale
+
+
+# ---------------------------------------------------------------------------------------------
+# image textures (albedo / roughness / normal map) of JSON materials.  No reference implementation on the
+# megakernel path and no reference-side vectors: parity is oracle <-> HIP only (unpinned).
+# ---------------------------------------------------------------------------------------------
+def _textured_cornell(O, pkg, res, env=False):
+    sc = O.cornell_box(res, res)
+    rng = np.random.default_rng(5)
+    n = sc.tri_count
+    # three textures back to back: 16x16 albedo checker with noise, 8x8 roughness, 32x32 normal-map bumps
+    def rgba(a):
+        out = np.zeros(a.shape[:2] + (4,), np.uint8)
+        out[..., :a.shape[2]] = a
+        out[..., 3] = 255
+        return out.reshape(-1, 4)
+    yy, xx = np.mgrid[0:16, 0:16]
+    albedo = (np.stack([((xx + yy) % 2) * 150 + 60, ((xx // 2 + yy) % 2) * 120 + 90, (yy * 13) % 200 + 40], -1) + rng.integers(0, 15, (16, 16, 3)))
+    rough = np.repeat(rng.integers(10, 250, (8, 8, 1)), 3, axis=2)
+    yy, xx = np.mgrid[0:32, 0:32]
+    nx, ny = 0.35 * np.sin(xx * 0.7), 0.35 * np.cos(yy * 0.9)
+    nz = np.sqrt(np.maximum(0, 1 - nx * nx - ny * ny))
+    nmap = np.stack([(nx * 0.5 + 0.5) * 255, (ny * 0.5 + 0.5) * 255, nz * 255], -1)
+    tex = [rgba(albedo.astype(np.uint8)), rgba(rough.astype(np.uint8)), rgba(nmap.astype(np.uint8))]
+    desc = np.array([[0, 16, 16], [256, 8, 8], [256 + 64, 32, 32]], np.int32)
+    none = 0xFFFFFFFF
+    mt = np.full((sc.bsdfs.shape[0], 4), none, np.uint32)
+    mt[:, 3] = np.float32(1.0).view(np.uint32)
+    mt[0] = [0, 1, 2, np.float32(1.0).view(np.uint32)]            # Oren-Nayar: albedo + roughness + normal map
+    mt[1] = [none, 1, 2, np.float32(0.6).view(np.uint32)]         # GGX dielectric: roughness (anisotropy 0.6) + normal map
+    mt[3] = [0, none, none, np.float32(1.0).view(np.uint32)]      # albedo only
+    mt[5] = [none, none, 2, np.float32(1.0).view(np.uint32)]      # normal map only
+    uv = rng.uniform(-0.5, 2.5, (n, 6)).astype(np.float32)        # beyond [0, 1]: exercises the mirror wrap
+    sc.set_textures(np.concatenate(tex), desc, mt, uv)
+    if env:
+        sc.set_envmap(pkg.host_scene.synthetic_sky(16))
+    return sc
+
+
+@pytest.mark.parametrize("accel, env", [(0, False), (1, False), (0, True), (1, True)])
+def test_textured_materials_vs_oracle(renderer, pkg, O, accel, env):
+    sc = _textured_cornell(O, pkg, 64, env)
+    renderer.upload_scene(sc)
+    renderer.set_limits(6)
+    renderer.set_accel(accel)
+    renderer.set_partition(0, 1)
+    try:
+        renderer.film_clear()
+        renderer.render(32)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
+        L = renderer.test_trace_samples(np.arange(64, dtype=np.int32) % 64, (np.arange(64, dtype=np.int32) * 7) % 64, np.arange(64, dtype=np.int32) % 5)
+    finally:
+        renderer.set_accel(0)
+        renderer.clear_envmap()
+        renderer.upload_textures(None, None, None, None)
+    om, om2 = O.render(sc, 32, max_depth=6, threads=8)[:2]
+    plain = O.cornell_box(64, 64)
+    if env:
+        plain.set_envmap(pkg.host_scene.synthetic_sky(16))
+    pm = O.render(plain, 32, max_depth=6, threads=8)[0]
+    assert np.array_equal(m2[..., 3], om2[..., 3]) and np.isfinite(mean).all() and np.isfinite(L).all()
+    scale = float(om[..., :3].mean())
+    assert film_rmse(om, pm) > 5e-3 * scale                      # the textures do change the picture
+    assert film_rmse(mean, om) < RMSE_TOL * max(1.0, scale), film_rmse(mean, om)
+
+
+def test_texture_upload_is_validated(renderer, pkg, O):
+    sc = _textured_cornell(O, pkg, 32)
+    renderer.upload_scene(sc)
+    bad = sc.tex_desc.copy()
+    bad[2, 1] = 4096                                             # descriptor runs past the texel array
+    with pytest.raises(pkg.DmtError, match="outside the texel array"):
+        renderer.upload_textures(sc.tex_rgba, bad, sc.mat_tex, sc.tri_uv)
+    mt = sc.mat_tex.copy()
+    mt[0, 0] = 7                                                 # texture index that does not exist
+    with pytest.raises(pkg.DmtError, match="does not exist"):
+        renderer.upload_textures(sc.tex_rgba, sc.tex_desc, mt, sc.tri_uv)
+    renderer.upload_textures(sc.tex_rgba, sc.tex_desc, sc.mat_tex, sc.tri_uv[:-1])   # wrong triangle count: caught at render time
+    with pytest.raises(pkg.DmtError, match="do not match"):
+        renderer.render(1)
+    renderer.upload_textures(None, None, None, None)
+    renderer.render(1)                                           # cleared: plain kernels again
+    renderer.sync()
+
