@@ -169,7 +169,7 @@ bool prop70(Node const& owner, char const* name, double* out, int n) {
 
 }  // namespace
 
-static bool readFbxMeshImpl(std::string const& path, std::vector<Triangle>& out, std::string* error) {
+static bool readFbxMeshImpl(std::string const& path, std::vector<Triangle>& out, std::string* error, std::vector<float>* uv6) {
   auto bad = [&](std::string const& m) {
     if (error) *error = path + ": " + m;
     return false;
@@ -236,17 +236,49 @@ static bool readFbxMeshImpl(std::string const& path, std::vector<Triangle>& out,
     P[i] = Vec3{float((M[0][0] * x + M[0][1] * y + M[0][2] * z + T[0]) * unit), float((M[1][0] * x + M[1][1] * y + M[1][2] * z + T[1]) * unit),
                 float((M[2][0] * x + M[2][1] * y + M[2][2] * z + T[2]) * unit)};
   }
+  // first LayerElementUV (what processUVLayerElement of core-mesh-parser.cpp reads): per polygon vertex ("ByPolygonVertex"),
+  // direct or through UVIndex; other mappings (by control point) are resolved through the vertex index
+  std::vector<double> const* UV = nullptr;
+  std::vector<double> const* UVI = nullptr;
+  bool uvByPolygonVertex = true;
+  if (Node const* le = geom->child("LayerElementUV")) {
+    if (Node const* a = le->child("UV"))
+      if (!a->props.empty()) UV = &a->props[0].arr;
+    if (Node const* a = le->child("UVIndex"))
+      if (!a->props.empty() && !a->props[0].arr.empty()) UVI = &a->props[0].arr;
+    if (Node const* a = le->child("MappingInformationType"))
+      if (!a->props.empty()) uvByPolygonVertex = a->props[0].str == "ByPolygonVertex";
+  }
+  auto cornerUv = [&](size_t corner, uint32_t vertex, float* uv) {  // corner = running index over PolygonVertexIndex
+    uv[0] = uv[1] = 0.f;
+    if (!UV || UV->empty()) return;
+    size_t const k = uvByPolygonVertex ? corner : size_t(vertex);
+    int64_t idx = UVI ? (k < UVI->size() ? int64_t((*UVI)[k]) : -1) : int64_t(k);
+    if (idx < 0 || size_t(2 * idx + 1) >= UV->size()) return;
+    uv[0] = float((*UV)[size_t(2 * idx)]), uv[1] = float((*UV)[size_t(2 * idx + 1)]);
+  };
   out.clear();
+  if (uv6) uv6->clear();
   std::vector<uint32_t> poly;
+  std::vector<size_t> polyCorner;
+  size_t corner = 0;
   for (double di : I) {
     int64_t idx = int64_t(di);
     bool const last = idx < 0;
     if (last) idx = ~idx;  // the last index of a polygon is stored as its bitwise complement
     if (idx < 0 || size_t(idx) >= nv) return bad("vertex index out of range");
     poly.push_back(uint32_t(idx));
+    polyCorner.push_back(corner++);
     if (last) {
-      for (size_t k = 1; k + 1 < poly.size(); ++k) out.push_back(Triangle{P[poly[0]], P[poly[k]], P[poly[k + 1]]});
-      poly.clear();
+      for (size_t k = 1; k + 1 < poly.size(); ++k) {
+        out.push_back(Triangle{P[poly[0]], P[poly[k]], P[poly[k + 1]]});
+        if (uv6) {
+          float uv[6];
+          cornerUv(polyCorner[0], poly[0], uv), cornerUv(polyCorner[k], poly[k], uv + 2), cornerUv(polyCorner[k + 1], poly[k + 1], uv + 4);
+          uv6->insert(uv6->end(), uv, uv + 6);
+        }
+      }
+      poly.clear(), polyCorner.clear();
     }
   }
   if (out.empty()) return bad("mesh has no polygons");
@@ -254,9 +286,9 @@ static bool readFbxMeshImpl(std::string const& path, std::vector<Triangle>& out,
 }
 
 // Files are untrusted input: nothing escapes as an exception (allocation failure on a forged size, ...).
-bool readFbxMesh(std::string const& path, std::vector<Triangle>& out, std::string* error) {
+bool readFbxMesh(std::string const& path, std::vector<Triangle>& out, std::string* error, std::vector<float>* uv6) {
   try {
-    return readFbxMeshImpl(path, out, error);
+    return readFbxMeshImpl(path, out, error, uv6);
   } catch (std::exception const& e) {
     if (error) *error = path + ": " + e.what();
   } catch (...) {

@@ -96,6 +96,13 @@ const float* dmt_host_scene_env_rgb(const dmt_host_scene* h, int* width, int* he
   if (height) *height = h->s.envHeight;
   return h->s.envRgb.empty() ? nullptr : h->s.envRgb.data();
 }
+// image textures: counts, then the four arrays in dmt_upload_textures' layout
+uint32_t dmt_host_scene_texture_count(const dmt_host_scene* h) { return uint32_t(h->s.texDesc.size() / 3); }
+uint64_t dmt_host_scene_texel_count(const dmt_host_scene* h) { return uint64_t(h->s.texRgba.size() / 4); }
+const uint8_t* dmt_host_scene_tex_rgba(const dmt_host_scene* h) { return h->s.texRgba.data(); }
+const int32_t* dmt_host_scene_tex_desc(const dmt_host_scene* h) { return h->s.texDesc.data(); }
+const uint32_t* dmt_host_scene_mat_tex(const dmt_host_scene* h) { return h->s.matTex.data(); }
+const float* dmt_host_scene_tri_uv(const dmt_host_scene* h) { return h->s.triUv.data(); }
 void dmt_host_scene_destroy(dmt_host_scene* h) { delete h; }
 
 uint64_t dmt_host_scene_triangle_count(const dmt_host_scene* h) { return h->s.triangleCount(); }

@@ -17,8 +17,8 @@
 // flat scene, so three mappings are this build's own and are documented in DESIGN.md: materials become ONE packed
 // BSDF record each ("oren-nayar-dielectric" -> Oren-Nayar; else metallic < 0.5 -> GGX dielectric, >= 0.5 -> GGX
 // conductor, alpha_y = roughness, alpha_x = anisotropy * roughness as core-material.cpp:262-263), instances are
-// flattened (every vertex transformed on the host), and image textures / normal maps are rejected with a clear error
-// (no texture unit on this path yet).  FBX objects go through this build's own binary reader (dmt_fbx.cpp).
+// flattened (every vertex transformed on the host), and image textures (albedo of Oren-Nayar materials, roughness, normal maps) are sampled per hit by the *_tex kernels
+// (dmt_upload_textures); a textured 'metallic' is rejected: the material's BSDF kind is chosen once, on the host.  FBX objects go through this build's own binary reader (dmt_fbx.cpp).
 #include <zlib.h>
 
 #include <cmath>
@@ -118,6 +118,7 @@ struct Material {
   float anisotropy = 1.f;  // (the reference leaves 0 when "ggx-anisotropy" is absent, which makes alpha_x = 0)
   Vec3 reflectanceTint{1, 1, 1}, transmittanceTint{1, 1, 1};
   bool orenNayar = false;
+  int32_t diffuseTex = -1, roughnessTex = -1, normalTex = -1;  // indices into State::textureList
 };
 struct LightProto {
   bool spot = false;
@@ -126,7 +127,12 @@ struct LightProto {
 };
 struct Mesh {
   std::vector<Triangle> tris;
+  std::vector<float> uv;  // six per triangle
   uint32_t material = 0;
+};
+struct Texture {
+  std::string type;
+  int32_t first = 0, width = 0, height = 0;  // texels in State::texels
 };
 
 // TriangleMesh::unitCube / unitPlane: positions and triangle order of core-trianglemesh.cpp:120-188
@@ -139,6 +145,19 @@ std::vector<Triangle> unitCube() {
   for (auto const& t : T) out.push_back(Triangle{P[t[0]], P[t[1]], P[t[2]]});
   return out;
 }
+// per-corner texture coordinates of unitCube / unitPlane (core-trianglemesh.cpp:103-156,174-185), six floats per triangle
+std::vector<float> unitCubeUv() {
+  float const t = 0.125f;
+  float const U[14][2] = {{3 * t, 0.f},   {5 * t, 0.f},   {5 * t, 2 * t}, {5 * t, 4 * t}, {7 * t, 4 * t}, {7 * t, 6 * t}, {5 * t, 6 * t},
+                          {5 * t, 1.f},   {3 * t, 1.f},   {3 * t, 6 * t}, {t, 6 * t},     {t, 4 * t},     {3 * t, 4 * t}, {3 * t, 2 * t}};
+  int const I[12][3] = {{6, 4, 5}, {6, 3, 4}, {9, 3, 6}, {9, 12, 3}, {9, 12, 10}, {9, 11, 12},
+                        {3, 12, 2}, {2, 12, 13}, {13, 1, 2}, {13, 0, 1}, {6, 7, 8}, {9, 6, 8}};
+  std::vector<float> out;
+  for (auto const& tri : I)
+    for (int c : tri) out.push_back(U[c][0]), out.push_back(U[c][1]);
+  return out;
+}
+std::vector<float> unitPlaneUv() { return {0, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1, 1}; }
 std::vector<Triangle> unitPlane() {
   float const h = 0.5f;
   Vec3 const P[4] = {{-h, -h, 0}, {h, -h, 0}, {-h, h, 0}, {h, h, 0}};
@@ -154,7 +173,9 @@ Packed32 packMaterial(Material const& m) {
 
 struct State {
   std::map<std::string, uint32_t> materials, objects;
-  std::map<std::string, std::string> textures;  // name -> type
+  std::map<std::string, uint32_t> textures;  // name -> index into textureList
+  std::vector<Texture> textureList;
+  std::vector<uint8_t> texels;               // RGBA8, all textures back to back
   std::map<std::string, LightProto> lights;
   std::map<std::string, Mat4> transforms;
   std::vector<Material> materialList;
@@ -192,7 +213,7 @@ void parseFilm(Value const& film, JsonScene& out) {
   if (out.scene.camera.width <= 0 || out.scene.camera.height <= 0) fail("film resolution should be positive");
 }
 
-void parseTexture(Value const& t, State& st) {
+void parseTexture(Value const& t, State& st, std::string const& baseDir) {
   if (!t.isObject()) fail("The 'textures' array should contain only objects");
   onlyKeys(t, {"name", "type", "path"}, "Texture object");
   if (!t.contains("name") || !t.at("name").isString()) fail("Texture object should contain attribute 'name' and it should be a string");
@@ -201,14 +222,37 @@ void parseTexture(Value const& t, State& st) {
   std::string const name = t.at("name").string, type = t.at("type").string;
   if (st.textures.count(name)) fail("texture " + name + " already exists");
   if (type != "diffuse" && type != "normal" && type != "metallic" && type != "roughness") fail("texture: unrecognized type '" + type + "'");
-  st.textures[name] = type;
+  // 8-bit PNGs (what the reference's scenes ship); channel rule of core-parser.cpp:373-386: diffuse / normal are
+  // 3-channel images, metallic / roughness 1-channel ones
+  std::vector<uint8_t> img;
+  int w = 0, h = 0, ch = 0;
+  std::string perr;
+  if (!readPng8(baseDir + "/" + t.at("path").string, img, w, h, ch, &perr)) fail("Error loading texture '" + name + "': " + perr);
+  bool const rgb = type == "diffuse" || type == "normal";
+  if (rgb ? ch < 3 : (ch != 1 && ch != 2)) fail("Error loading texture '" + name + "': metallic, roughness expect 1 channel; diffuse, normal expect 3 channels");
+  Texture tex;
+  tex.type = type, tex.first = int32_t(st.texels.size() / 4), tex.width = w, tex.height = h;
+  st.texels.reserve(st.texels.size() + size_t(w) * size_t(h) * 4);
+  for (size_t i = 0; i < size_t(w) * size_t(h); ++i) {
+    uint8_t const* p = &img[i * size_t(ch)];
+    uint8_t const r = p[0], g = rgb ? p[1] : p[0], b = rgb ? p[2] : p[0];
+    st.texels.insert(st.texels.end(), {r, g, b, uint8_t(255)});
+  }
+  st.textures[name] = uint32_t(st.textureList.size());
+  st.textureList.push_back(tex);
 }
 
-float scalarOrTexture(Value const& v, char const* key, State const& st) {
+// number, or the name of a texture of type `key` (returned through `tex`; the scalar then is the type's neutral value)
+float scalarOrTexture(Value const& v, char const* key, State const& st, int32_t* tex) {
   if (v.isNumber()) return clampf(float(v.number), 0.f, 1.f);
   if (v.isString()) {
     if (!st.textures.count(v.string)) fail(std::string("'") + key + "' texture name should be an existing named texture");
-    fail(std::string("material '") + key + "' refers to texture '" + v.string + "': image textures are not supported on the megakernel path");
+    Texture const& t = st.textureList[st.textures.at(v.string)];
+    if (t.type != key) fail(std::string("'") + key + "' material texture should point to a '" + key + "' texture");
+    if (!tex) fail(std::string("material '") + key + "' refers to texture '" + v.string + "': a textured '" + key +
+                   "' is not supported on the megakernel path (one BSDF kind per material)");
+    *tex = int32_t(st.textures.at(v.string));
+    return 0.5f;
   }
   fail(std::string("material '") + key + "' should be either texture name or number");
 }
@@ -232,13 +276,19 @@ void parseMaterial(Value const& m, State& st) {
     mat.diffuse = Vec3{q(d.x), q(d.y), q(d.z)};
   } else if (m.at("diffuse").isString()) {
     if (!st.textures.count(m.at("diffuse").string)) fail("'diffuse' texture name should be an existing named texture");
-    fail("material 'diffuse' refers to texture '" + m.at("diffuse").string + "': image textures are not supported on the megakernel path");
+    if (st.textureList[st.textures.at(m.at("diffuse").string)].type != "diffuse") fail("'diffuse' material texture should point to a 'diffuse' texture");
+    mat.diffuseTex = int32_t(st.textures.at(m.at("diffuse").string));
   } else {
     fail("material 'diffuse' should be either texture name or RGB");
   }
-  if (m.contains("normal")) fail("material 'normal': normal maps are not supported on the megakernel path");
-  mat.roughness = scalarOrTexture(m.at("roughness"), "roughness", st);
-  mat.metallic = scalarOrTexture(m.at("metallic"), "metallic", st);
+  if (m.contains("normal")) {  // core-parser.cpp:507-534
+    if (!m.at("normal").isString()) fail("material 'normal' should be an RGB texture name");
+    if (!st.textures.count(m.at("normal").string)) fail("'normal' texture name should be an existing named texture");
+    if (st.textureList[st.textures.at(m.at("normal").string)].type != "normal") fail("'normal' material texture should point to a 'normal' texture");
+    mat.normalTex = int32_t(st.textures.at(m.at("normal").string));
+  }
+  mat.roughness = scalarOrTexture(m.at("roughness"), "roughness", st, &mat.roughnessTex);
+  mat.metallic = scalarOrTexture(m.at("metallic"), "metallic", st, nullptr);
   if (m.contains("ior")) {
     if (!m.at("ior").isNumber()) fail("material 'ior' should be a number");
     mat.ior = std::fmax(float(m.at("ior").number), 1.f);
@@ -304,13 +354,13 @@ void parseObject(Value const& o, State& st, std::string const& baseDir) {
     onlyKeys(o, {"name", "type", "material", "path"}, "object '" + name + "'");
     if (!o.contains("path") || !o.at("path").isString()) fail("object '" + name + "' should have a 'path' string");
     std::string ferr;
-    if (!readFbxMesh(baseDir + "/" + o.at("path").string, mesh.tris, &ferr)) fail("object '" + name + "': " + ferr);
+    if (!readFbxMesh(baseDir + "/" + o.at("path").string, mesh.tris, &ferr, &mesh.uv)) fail("object '" + name + "': " + ferr);
   } else if (type == "primitive") {
     onlyKeys(o, {"name", "type", "material", "shape"}, "object '" + name + "'");
     if (!o.contains("shape") || !o.at("shape").isString()) fail("object '" + name + "' should have a 'shape' string");
     std::string const shape = o.at("shape").string;
-    if (shape == "cube") mesh.tris = unitCube();
-    else if (shape == "plane") mesh.tris = unitPlane();
+    if (shape == "cube") mesh.tris = unitCube(), mesh.uv = unitCubeUv();
+    else if (shape == "plane") mesh.tris = unitPlane(), mesh.uv = unitPlaneUv();
     else fail("object '" + name + "': unrecognized shape '" + shape + "'");
   } else {
     fail("object '" + name + "': unrecognized type '" + type + "'");
@@ -410,8 +460,11 @@ void walkWorld(Value const& node, State& st, Scene& sc) {  // parseWorldTranform
       for (auto const& o : value.array) {
         if (!o.isString() || !st.objects.count(o.string)) fail("'instances' refers to an unknown object");
         Mesh const& mesh = st.meshes[st.objects.at(o.string)];
-        for (Triangle const& t : mesh.tris)
+        for (size_t k = 0; k < mesh.tris.size(); ++k) {
+          Triangle const& t = mesh.tris[k];
           emitTriangle(sc, Triangle{xformPoint(cur, t.v0), xformPoint(cur, t.v1), xformPoint(cur, t.v2)}, mesh.material);
+          for (int j = 0; j < 6; ++j) sc.triUv.push_back(6 * k + size_t(j) < mesh.uv.size() ? mesh.uv[6 * k + size_t(j)] : 0.f);
+        }
       }
     } else if (key == "lights") {
       if (!value.isArray()) fail("'lights' should be an array of light names");
@@ -429,7 +482,7 @@ void walkWorld(Value const& node, State& st, Scene& sc) {  // parseWorldTranform
 }  // namespace
 
 // ---- PNG reader: 8-bit grey / RGB / RGBA, non-interlaced (what the env maps of the reference's scenes are) ------
-bool readPngRgb(std::string const& path, std::vector<float>& rgb, int& width, int& height, std::string* error) {
+bool readPng8(std::string const& path, std::vector<uint8_t>& img, int& width, int& height, int& channels, std::string* error) {
   auto bad = [&](char const* m) {
     if (error) *error = path + ": " + m;
     return false;
@@ -441,7 +494,7 @@ bool readPngRgb(std::string const& path, std::vector<float>& rgb, int& width, in
   if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) return bad("not a PNG file");
   auto be32 = [&](size_t o) { return (uint32_t(file[o]) << 24) | (uint32_t(file[o + 1]) << 16) | (uint32_t(file[o + 2]) << 8) | uint32_t(file[o + 3]); };
   uint32_t w = 0, h = 0;
-  int channels = 0;
+  channels = 0;
   std::vector<unsigned char> idat;
   for (size_t o = 8; o + 12 <= file.size();) {
     uint32_t const len = be32(o);
@@ -467,7 +520,7 @@ bool readPngRgb(std::string const& path, std::vector<float>& rgb, int& width, in
   std::vector<unsigned char> raw((stride + 1) * size_t(h));
   uLongf rawLen = uLongf(raw.size());
   if (uncompress(raw.data(), &rawLen, idat.data(), uLong(idat.size())) != Z_OK || rawLen != raw.size()) return bad("zlib stream does not match the image size");
-  std::vector<unsigned char> img(stride * size_t(h));
+  img.assign(stride * size_t(h), 0);
   for (size_t y = 0; y < h; ++y) {  // undo the per-row filters (PNG spec 9.2)
     unsigned char const* in = &raw[y * (stride + 1)];
     unsigned char* out = &img[y * stride];
@@ -493,8 +546,15 @@ bool readPngRgb(std::string const& path, std::vector<float>& rgb, int& width, in
     }
   }
   width = int(w), height = int(h);
-  rgb.resize(size_t(w) * size_t(h) * 3);
-  for (size_t i = 0; i < size_t(w) * size_t(h); ++i) {  // loadImageAsRGB: byte / 255, grey replicated
+  return true;
+}
+bool readPngRgb(std::string const& path, std::vector<float>& rgb, int& width, int& height, std::string* error) {
+  std::vector<uint8_t> img;
+  int channels = 0;
+  if (!readPng8(path, img, width, height, channels, error)) return false;
+  size_t const n = size_t(width) * size_t(height);
+  rgb.resize(n * 3);
+  for (size_t i = 0; i < n; ++i) {  // loadImageAsRGB: byte / 255, grey replicated
     unsigned char const* p = &img[i * size_t(channels)];
     if (channels >= 3) rgb[3 * i] = p[0] / 255.0f, rgb[3 * i + 1] = p[1] / 255.0f, rgb[3 * i + 2] = p[2] / 255.0f;
     else rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = p[0] / 255.0f;
@@ -530,7 +590,7 @@ bool loadJsonScene(std::string const& path, JsonScene& out, std::string* error) 
     out.scene.camera.pos[0] = pos.x, out.scene.camera.pos[1] = pos.y, out.scene.camera.pos[2] = pos.z;
     out.scene.camera.spp = out.samplesPerPixel;
     if (!data.at("textures").isArray()) fail("'textures' should be a JSON array");
-    for (auto const& t : data.at("textures").array) parseTexture(t, st);
+    for (auto const& t : data.at("textures").array) parseTexture(t, st, directoryOf(path));
     if (!data.at("materials").isArray()) fail("'materials' should be a JSON array");
     for (auto const& m : data.at("materials").array) parseMaterial(m, st);
     if (!data.at("objects").isArray()) fail("'objects' should be a JSON array");
@@ -553,6 +613,20 @@ bool loadJsonScene(std::string const& path, JsonScene& out, std::string* error) 
       st.stack.pop_back();
     }
     for (Material const& m : st.materialList) out.scene.bsdfs.push_back(packMaterial(m));
+    // image textures: only when some material uses one (otherwise the plain kernels run and nothing is uploaded)
+    bool textured = false;
+    for (Material const& m : st.materialList) textured = textured || m.diffuseTex >= 0 || m.roughnessTex >= 0 || m.normalTex >= 0;
+    if (textured) {
+      out.scene.texRgba = std::move(st.texels);
+      for (Texture const& t : st.textureList) out.scene.texDesc.insert(out.scene.texDesc.end(), {t.first, t.width, t.height});
+      for (Material const& m : st.materialList) {
+        uint32_t bits;
+        memcpy(&bits, &m.anisotropy, 4);
+        out.scene.matTex.insert(out.scene.matTex.end(), {uint32_t(m.diffuseTex), uint32_t(m.roughnessTex), uint32_t(m.normalTex), bits});
+      }
+    } else {
+      out.scene.triUv.clear();
+    }
     return true;
   } catch (Fail const& e) {
     if (error) *error = e.msg;

@@ -400,8 +400,12 @@ int uploadScene(dmt_ctx* ctx, Scene const& s) {
   if (rc) return rc;
   rc = dmt_upload_area_lights(ctx, s.areaTri.data(), s.areaLe.data(), uint32_t(s.areaTri.size()));
   if (rc) return rc;
-  if (!s.envRgb.empty()) return dmt_upload_envmap(ctx, s.envRgb.data(), s.envWidth, s.envHeight, s.envQuat, s.envScale);
-  return dmt_clear_envmap(ctx);
+  rc = s.envRgb.empty() ? dmt_clear_envmap(ctx) : dmt_upload_envmap(ctx, s.envRgb.data(), s.envWidth, s.envHeight, s.envQuat, s.envScale);
+  if (rc) return rc;
+  if (s.texDesc.empty())
+    return dmt_upload_textures(ctx, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0);
+  return dmt_upload_textures(ctx, s.texRgba.data(), s.texRgba.size() / 4, s.texDesc.data(), uint32_t(s.texDesc.size() / 3), s.matTex.data(),
+                             uint32_t(s.matTex.size() / 4), s.triUv.data(), s.triUv.size() / 6);
 }
 
 }  // namespace dmt_host

@@ -68,6 +68,13 @@ struct Scene {
   // and rgb radiance per entry
   std::vector<uint32_t> areaTri;
   std::vector<float> areaLe;
+  // optional image textures (the JSON front-end's "textures"), in dmt_upload_textures' layout: RGBA8 texels
+  // of all textures back to back, {first texel, width, height} per texture, {diffuse, roughness, normal texture or
+  // 0xFFFFFFFF, anisotropy float bits} per BSDF, {u0 v0 u1 v1 u2 v2} per triangle
+  std::vector<uint8_t> texRgba;
+  std::vector<int32_t> texDesc;
+  std::vector<uint32_t> matTex;
+  std::vector<float> triUv;
 
   size_t triangleCount() const { return matId.size(); }
   // addModel + the material walk of triSoupFromTriangles: the FIRST mesh always gets material 0
@@ -106,11 +113,14 @@ struct PbrtScene {
   int samplesPerPixel = 16;  // pbrt's sampler default
 };
 bool loadPbrtScene(std::string const& path, PbrtScene& out, std::string* error = nullptr);
-// binary FBX (Kaydara 7100+): first mesh, fan-triangulated, Model TRS and unit scale applied (host/dmt_fbx.cpp)
-bool readFbxMesh(std::string const& path, std::vector<Triangle>& out, std::string* error = nullptr);
+// binary FBX (Kaydara 7100+): first mesh, fan-triangulated, Model TRS and unit scale applied (host/dmt_fbx.cpp); uv6: optional,
+// six floats per triangle from the mesh's first LayerElementUV (zeros when the file has none)
+bool readFbxMesh(std::string const& path, std::vector<Triangle>& out, std::string* error = nullptr, std::vector<float>* uv6 = nullptr);
 // 8-bit grey / RGB / RGBA non-interlaced PNG -> RGB floats, byte / 255 as the reference's loadImageAsRGB
 // (core-parser.cpp:156-167)
 bool readPngRgb(std::string const& path, std::vector<float>& rgb, int& width, int& height, std::string* error = nullptr);
+// the same decoder, bytes as stored: channels = 1 (grey), 2, 3 or 4 per pixel
+bool readPng8(std::string const& path, std::vector<uint8_t>& pixels, int& width, int& height, int& channels, std::string* error = nullptr);
 
 // 8-bit images of the film, exactly as the reference's writers quantise them
 // (CC/private/host_utils.cu:475-497): u8 = (uint8)min(max(v,0)*255, 255), linear, truncating;

@@ -68,6 +68,17 @@ class HostScene:
         na = L.dmt_host_scene_area_light_count(h)
         self.area_tri = _copy(L.dmt_host_scene_area_tri(h), np.uint32, na)
         self.area_le = _copy(L.dmt_host_scene_area_le(h), np.float32, 3 * na).reshape(-1, 3)
+        L.dmt_host_scene_texture_count.restype = C.c_uint32
+        L.dmt_host_scene_texel_count.restype = C.c_uint64
+        nt = L.dmt_host_scene_texture_count(h)
+        self.tex_desc = self.tex_rgba = self.mat_tex = self.tri_uv = None
+        if nt:
+            for name in ("dmt_host_scene_tex_rgba", "dmt_host_scene_tex_desc", "dmt_host_scene_mat_tex", "dmt_host_scene_tri_uv"):
+                getattr(L, name).restype = C.c_void_p
+            self.tex_rgba = _copy(L.dmt_host_scene_tex_rgba(h), np.uint8, 4 * L.dmt_host_scene_texel_count(h)).reshape(-1, 4)
+            self.tex_desc = _copy(L.dmt_host_scene_tex_desc(h), np.int32, 3 * nt).reshape(-1, 3)
+            self.mat_tex = _copy(L.dmt_host_scene_mat_tex(h), np.uint32, 4 * self.bsdfs.shape[0]).reshape(-1, 4)
+            self.tri_uv = _copy(L.dmt_host_scene_tri_uv(h), np.float32, 6 * n).reshape(-1, 6)
         L.dmt_host_scene_destroy(h)
 
     @property

@@ -151,6 +151,42 @@ def test_reference_scene_example_json(renderer, pkg, O, accel):
     assert scale > 0.1 and film_rmse(mean, om) < RMSE_TOL * max(1.0, scale)
 
 
+def test_reference_scene_test_json_textured_teapot(renderer, pkg, O):
+    """The reference's scenes/scene_test.json unmodified: teapot.fbx (9 216 triangles with its own UVs) in chipped paint --
+    albedo, roughness and normal-map PNGs -- under an env map (stand-in file, see tests/test_json_scene.py): BVH + env-map
+    + texture kernel at the file's film and sample count vs the oracle on row bands."""
+    hs = pkg.host_scene.load_json(GOLDEN / "scene_test" / "scene_test.json")
+    osc = O.Scene(hs.xs, hs.ys, hs.zs, hs.mat_id, hs.bsdfs, hs.lights, hs.inf_lights, hs.camera)
+    osc.set_envmap(hs.env_rgb)
+    osc.set_textures(hs.tex_rgba, hs.tex_desc, hs.mat_tex, hs.tri_uv)
+    w, h = hs.width, hs.height
+    renderer.upload_scene(hs)
+    renderer.set_limits(hs.max_depth)
+    renderer.set_accel(1)
+    renderer.set_partition(0, 1)
+    try:
+        renderer.film_clear()
+        renderer.render(hs.spp)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
+        renderer.upload_textures(None, None, None, None)          # the same scene without its textures
+        renderer.film_clear()
+        renderer.render(hs.spp)
+        renderer.sync()
+        plain, _ = renderer.download_film()
+    finally:
+        renderer.set_accel(0)
+        renderer.clear_envmap()
+        renderer.upload_textures(None, None, None, None)
+    assert np.isfinite(mean).all() and np.all(m2[..., 3] == hs.spp)
+    scale = float(mean[..., :3].mean())
+    assert film_rmse(mean, plain) > 2e-3 * scale                  # roughness texture + normal map change the teapot
+    for y0, y1 in _band_rows(h, 4, 3):
+        om, om2 = O.render(osc, hs.spp, max_depth=hs.max_depth, region=(0, y0, w, y1), threads=16)[:2]
+        assert np.array_equal(m2[y0:y1, :, 3], om2[y0:y1, :, 3])
+        assert film_rmse(mean[y0:y1], om[y0:y1]) < RMSE_TOL * max(1.0, scale), y0
+
+
 def test_c5_frame_4096_reduced_spp(renderer, O):
     """BASELINE configs[4]'s frame on one GPU: 4096 x 4096, samples 4092..4095 (the last sample indices of the
     4096-spp run: largest Halton indices of the config), cap 8."""
