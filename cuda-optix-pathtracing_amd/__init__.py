@@ -12,6 +12,7 @@ from .binding import (  # noqa: F401
     DmtError,
     Renderer,
     bvh_validate,
+    light_tree_pmfs,
     envmap_tables,
     build_library,
     library_path,

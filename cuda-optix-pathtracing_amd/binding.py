@@ -51,7 +51,7 @@ def load_library():
 # every symbol include/dmt_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTED_SYMBOLS = [
     "dmt_ctx_create", "dmt_ctx_destroy", "dmt_last_error", "dmt_upload_triangles", "dmt_upload_bsdfs",
-    "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_bvh_strategy", "dmt_set_partition", "dmt_set_chunk", "dmt_render_profile",
+    "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_light_sampling", "dmt_light_tree_pmfs", "dmt_set_bvh_strategy", "dmt_set_partition", "dmt_set_chunk", "dmt_render_profile",
     "dmt_upload_area_lights", "dmt_upload_textures", "dmt_upload_envmap", "dmt_clear_envmap", "dmt_envmap_tables", "dmt_test_envmap",
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
     "dmt_render", "dmt_render_stats", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
@@ -71,6 +71,18 @@ def _f32(a, shape=None):
 
 def _i32(a):
     return np.ascontiguousarray(a, np.int32).reshape(-1)
+
+
+def light_tree_pmfs(lights32, p, n):
+    """Host-only: selection probability of every packed light at point p with normal n; returns (pmfs, node_count, depth)."""
+    lib = load_library()
+    L = np.ascontiguousarray(lights32, np.uint8).reshape(-1, 32)
+    out = np.zeros(L.shape[0], np.float32)
+    nc, d = C.c_int(), C.c_int()
+    rc = lib.dmt_light_tree_pmfs(_p(L), C.c_uint32(L.shape[0]), _p(_f32(p, (3,))), _p(_f32(n, (3,))), _p(out), C.byref(nc), C.byref(d))
+    if rc != 0:
+        raise DmtError(f"dmt_light_tree_pmfs failed ({rc})")
+    return out, nc.value, d.value
 
 
 def bvh_validate(xs, ys, zs):
@@ -223,6 +235,10 @@ class Renderer:
 
     def set_accel(self, mode):
         self._check(self._lib.dmt_set_accel(self._ctx, int(mode)), "dmt_set_accel")
+
+    def set_light_sampling(self, mode):
+        """0 = uniform pick (reference, parity mode), 1 = light tree (csrc/light_tree.hpp)."""
+        self._check(self._lib.dmt_set_light_sampling(self._ctx, int(mode)), "dmt_set_light_sampling")
 
     def set_bvh_strategy(self, strategy, paths_per_pass=0):
         """0 = automatic, 1 = megakernel, 2 = device-side wavefront (films are bit-identical)."""

@@ -30,6 +30,7 @@
 #include "pt_device.hpp"
 #include "bvh_device.hpp"
 #include "envmap.hpp"
+#include "light_tree.hpp"
 
 using namespace dmt;
 
@@ -67,6 +68,7 @@ struct RenderParams {
   int32_t const* texDesc;     // [texture] {first texel, width, height}
   uint32_t const* matTex;     // [bsdf] {diffuse, roughness, normal texture or 0xFFFFFFFF, anisotropy as float bits}
   float const* triUv;         // [triangle] {u0, v0, u1, v1, u2, v2}
+  LightTreeNode const* lightTree;  // light BVH over `lights` (light_tree.hpp); read by the *_ltree kernels only
   unsigned long long* stats;  // stats build only: samples, closest rays, shadow rays, node visits, triangle tests, bounces
 };
 
@@ -296,7 +298,7 @@ DMT_DEV f3 apply_material_textures(KArgs k, Rec32& rec, uint32_t matId, int tri,
   return (l2 > 0.f && l2 < kInf) ? ns / sqrtf(l2) : ng;
 }
 
-template <bool ENV = false, bool AREA = false, bool TEX = false>
+template <bool ENV = false, bool AREA = false, bool TEX = false, bool LTREE = false>
 DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv) {
   SceneView const sc = load_scene(k);
   int const maxDepth = kargs(k)->maxDepth;
@@ -396,11 +398,22 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
     }
   }
   if (!envNee && !areaNee && sc.lightCount > 0) {
-    uint32_t const li = pick_index(uLight, AREA ? nAll : sc.lightCount);
+    uint32_t li = 0;
+    float pmf = 0.f;
+    bool picked = true;
+    if constexpr (LTREE) {  // importance-driven choice (light_tree.hpp) instead of the uniform pick
+      float treePmf = 0.f;
+      int const sel = lt_select(kargs(k)->lightTree, hit.pos.x, hit.pos.y, hit.pos.z, hit.normal.x, hit.normal.y, hit.normal.z, uLight, treePmf);
+      picked = sel >= 0;
+      li = picked ? uint32_t(sel) : 0u;
+      pmf = (ENV ? 0.5f : 1.f) * treePmf;
+    } else {
+      li = pick_index(uLight, AREA ? nAll : sc.lightCount);
+      pmf = (ENV ? 0.5f : 1.f) / float(AREA ? nAll : sc.lightCount);
+    }
     Rec32 const light = sc.lights[li];
-    float const pmf = (ENV ? 0.5f : 1.f) / float(AREA ? nAll : sc.lightCount);
     LightSample const ls = sample_light(light, hit.pos, uLight2, st.lastT, hit.normal);
-    if (ls.valid()) {
+    if (picked && ls.valid()) {
       float bsdfPdf = 0.f;
       f3 const f = eval_bsdf(b, wo, ls.direction, ns, hit.normal, bsdfPdf) * b.weight;
       if (!is_zero(f)) {
@@ -523,11 +536,11 @@ DMT_DEV void trace_pair_bvh(KArgs k, PathState const& st, bool doC, bool doS, ui
 
 // One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
 // sink(L, sidx) is called once per completed sample with the index the sample was started with.
-template <bool ENV = false, bool AREA = false, bool TEX = false, class Sink>
+template <bool ENV = false, bool AREA = false, bool TEX = false, bool LTREE = false, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink);
 
-template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false, class Sink>
+template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false, bool LTREE = false, class Sink>
 DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneStats* ls = nullptr) {
   bool const doC = st.active;
   bool const doS = st.hasShadow;
@@ -539,11 +552,11 @@ DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneS
   else
     trace_pair_brute(k, st, doC, doS, bestTri, bu, bv, occluded);
   if constexpr (STATS) ls->bounces += (doC && bestTri >= 0 && st.depth < kargs(k)->maxDepth) ? 1u : 0u;
-  lane_finish<ENV, AREA, TEX>(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
+  lane_finish<ENV, AREA, TEX, LTREE>(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
 }
 
 // Second half of a ray pass: resolve the shadow ray (in the reference's accumulation order), then shade.
-template <bool ENV, bool AREA, bool TEX, class Sink>
+template <bool ENV, bool AREA, bool TEX, bool LTREE, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink) {
   if (doS) {
@@ -558,7 +571,7 @@ DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri
     }
   }
   if (doC) {
-    if (path_shade<ENV, AREA, TEX>(k, st, bestTri, bu, bv)) {
+    if (path_shade<ENV, AREA, TEX, LTREE>(k, st, bestTri, bu, bv)) {
       st.active = false;
       if (st.hasShadow) {  // last NEE still untraced: park the sample, the lane may start the next
         put_Lfin(st.L);
@@ -905,7 +918,7 @@ DMT_DEV void flush_stats(KArgs Pk, LaneStats const& ls) {
   }
 }
 
-template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false>
+template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false, bool LTREE = false>
 DMT_DEV void megakernel_body() {
   KArgs const Pk = kargs_base();
   LaneStats ls;
@@ -936,7 +949,7 @@ DMT_DEV void megakernel_body() {
           }
         }
       }
-      lane_step<BVH, STATS, ENV, AREA, TEX>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
+      lane_step<BVH, STATS, ENV, AREA, TEX, LTREE>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
     }
   }
   flush_stats<STATS>(Pk, ls);
@@ -958,7 +971,7 @@ DMT_DEV void megakernel_body() {
 #ifndef DMT_BVH_DUMMY_LDS
 #define DMT_BVH_DUMMY_LDS 0  // occupancy experiments: extra LDS bytes per block (fewer resident blocks per CU)
 #endif
-template <bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false>
+template <bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false, bool LTREE = false>
 DMT_DEV void megakernel_body_bvh() {
   KArgs const Pk = kargs_base();
 #if DMT_BVH_DUMMY_LDS > 0
@@ -1062,7 +1075,7 @@ DMT_DEV void megakernel_body_bvh() {
       if constexpr (STATS) ++ls.itShade, ls.lanesShade += tv.phase == TR_DONE ? 1u : 0u;
       if (tv.phase == TR_DONE) {
         if constexpr (STATS) ls.bounces += (tv.doC && tv.bestTri >= 0 && st.depth < kargs(Pk)->maxDepth) ? 1u : 0u;
-        lane_finish<ENV, AREA, TEX>(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
+        lane_finish<ENV, AREA, TEX, LTREE>(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
         tv.phase = TR_IDLE;
       }
     }
@@ -1090,6 +1103,11 @@ __global__ void __launch_bounds__(256, 4) k_megakernel_tex(RenderParams P) { meg
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_tex(RenderParams P) { megakernel_body_bvh<false, false, false, true>(); }
 __global__ void __launch_bounds__(256, 4) k_megakernel_env_tex(RenderParams P) { megakernel_body<false, false, true, false, true>(); }
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_env_tex(RenderParams P) { megakernel_body_bvh<false, true, false, true>(); }
+// light tree compiled in (dmt_set_light_sampling(DMT_LIGHTS_TREE) selects them); with or without the env map
+__global__ void __launch_bounds__(256, 4) k_megakernel_ltree(RenderParams P) { megakernel_body<false, false, false, false, false, true>(); }
+__global__ void __launch_bounds__(256, 3) k_megakernel_bvh_ltree(RenderParams P) { megakernel_body_bvh<false, false, false, false, true>(); }
+__global__ void __launch_bounds__(256, 4) k_megakernel_env_ltree(RenderParams P) { megakernel_body<false, false, true, false, false, true>(); }
+__global__ void __launch_bounds__(256, 3) k_megakernel_bvh_env_ltree(RenderParams P) { megakernel_body_bvh<false, true, false, false, true>(); }
 // both optional light kinds at once
 __global__ void __launch_bounds__(256, 4) k_megakernel_env_area(RenderParams P) { megakernel_body<false, false, true, true>(); }
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_env_area(RenderParams P) { megakernel_body_bvh<false, true, true>(); }
@@ -1113,7 +1131,18 @@ __global__ void k_test_trace(RenderParams P, bool useBvh, int n, int32_t const* 
   for (;;) {
     if (!__any(st.active || st.hasShadow)) break;
     bool const useEnv = kargs(k)->env.w > 0;
-    if (kargs(k)->matTex != nullptr) {
+    if (kargs(k)->lightTree != nullptr) {
+      if (useEnv) {
+        if (useBvh)
+          lane_step<true, false, true, false, false, true>(k, gtid, st, store);
+        else
+          lane_step<false, false, true, false, false, true>(k, gtid, st, store);
+      } else if (useBvh) {
+        lane_step<true, false, false, false, false, true>(k, gtid, st, store);
+      } else {
+        lane_step<false, false, false, false, false, true>(k, gtid, st, store);
+      }
+    } else if (kargs(k)->matTex != nullptr) {
       if (useEnv) {
         if (useBvh)
           lane_step<true, false, true, false, true>(k, gtid, st, store);
@@ -1354,6 +1383,13 @@ struct dmt_ctx {
   int bvhDepth = 0;
   uint32_t bvhNodeCount = 0, bvhPairCount = 0;
   int blocksPerCUBvh = 0;
+  // light tree (light_tree.hpp): built from the uploaded lights when dmt_set_light_sampling asks for it
+  int lightSampling = DMT_LIGHTS_UNIFORM;
+  std::vector<uint8_t> h_lights;  // host copy of the packed light records
+  LightTreeNode* d_lightTree = nullptr;
+  uint32_t lightTreeNodes = 0;
+  int lightTreeDepth = 0;
+  bool lightTreeValid = false;
   std::vector<std::pair<void const*, int>> occupancy;  // megakernel variant -> resident 256-thread blocks per CU
   // SURVEY 8f-1 image textures (one allocation each)
   uint32_t* d_texRgba = nullptr;
@@ -1411,6 +1447,27 @@ struct dmt_ctx {
 namespace {
 
 std::string g_createError;
+
+float h2f_host(uint16_t h) {  // exact fp16 -> fp32 (CC/private/encoding.cu:124-155)
+  uint32_t const sgn = uint32_t(h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1Fu, m = h & 0x3FFu, out;
+  if (e == 0) {
+    if (m == 0) {
+      out = sgn;
+    } else {
+      e = 113;
+      while (!(m & 0x400u)) m <<= 1, --e;
+      out = sgn | (e << 23) | ((m & 0x3FFu) << 13);
+    }
+  } else if (e == 31) {
+    out = sgn | 0x7F800000u | (m << 13);
+  } else {
+    out = sgn | ((e + 112) << 23) | (m << 13);
+  }
+  float f;
+  memcpy(&f, &out, 4);
+  return f;
+}
 
 #define HIP_TRY(ctx, call)                                                                 \
   do {                                                                                     \
@@ -1484,6 +1541,12 @@ SamplerParams computeSamplerParams(int width, int height) {
   return p;
 }
 
+// the light tree applies to plain point / spot light lists; textured or emissive-triangle scenes keep the uniform pick
+bool useLightTree(dmt_ctx const* c) {
+  return c->lightSampling == DMT_LIGHTS_TREE && c->lightCount > 1 && c->areaCount == 0 && c->texCount == 0;
+}
+int ensureLightTree(dmt_ctx* ctx);
+
 SceneView sceneView(dmt_ctx const* c) {
   SceneView s;
   s.tris = c->d_tris, s.post = c->d_post, s.bsdfs = c->d_bsdfs, s.lights = c->d_lights;
@@ -1511,6 +1574,7 @@ RenderParams baseParams(dmt_ctx const* c, size_t threads) {
   P.env = c->env;
   P.areaOf = c->d_areaOf, P.areaTri = c->d_areaTri, P.areaLe = c->d_areaLe, P.areaCount = c->areaCount;
   if (c->texCount > 0) P.texRgba = c->d_texRgba, P.texDesc = c->d_texDesc, P.matTex = c->d_matTex, P.triUv = c->d_triUv;
+  if (useLightTree(c) && c->lightTreeValid) P.lightTree = c->d_lightTree;
   return P;
 }
 
@@ -1519,6 +1583,7 @@ typedef void (*MegakernelFn)(RenderParams);
 MegakernelFn megakernelOf(dmt_ctx const* c) {
   bool const bvh = c->accel == DMT_ACCEL_BVH, env = c->env.w > 0, area = c->areaCount > 0, tex = c->texCount > 0;
   if (tex) return bvh ? (env ? k_megakernel_bvh_env_tex : k_megakernel_bvh_tex) : (env ? k_megakernel_env_tex : k_megakernel_tex);
+  if (useLightTree(c)) return bvh ? (env ? k_megakernel_bvh_env_ltree : k_megakernel_bvh_ltree) : (env ? k_megakernel_env_ltree : k_megakernel_ltree);
   if (area && env) return bvh ? k_megakernel_bvh_env_area : k_megakernel_env_area;
   if (area) return bvh ? k_megakernel_bvh_area : k_megakernel_area;
   if (env) return bvh ? k_megakernel_bvh_env : k_megakernel_env;
@@ -1586,6 +1651,26 @@ int buildBvh(dmt_ctx* ctx) {
   ctx->bvhNodeCount = uint32_t(r.nodes.size());
   ctx->bvhPairCount = uint32_t(pairs.size());
   ctx->haveBvh = true;
+  return DMT_OK;
+}
+
+// (re)build the light tree from the host copy of the light records and upload it
+int ensureLightTree(dmt_ctx* ctx) {
+  if (ctx->lightTreeValid) return DMT_OK;
+  std::vector<light_tree::Item> items;
+  for (uint32_t i = 0; i < ctx->lightCount; ++i) {
+    light_tree::Item it{};
+    if (!light_tree::itemOf(ctx->h_lights.data() + 32 * size_t(i), i, [](uint16_t h) { return h2f_host(h); }, it))
+      return fail(ctx, DMT_ERR_STATE, "light tree: only point and spot lights can be in the light list");
+    items.push_back(it);
+  }
+  std::vector<LightTreeNode> const nodes = light_tree::build(items, &ctx->lightTreeDepth);
+  if (ctx->lightTreeDepth > 60) return fail(ctx, DMT_ERR_STATE, "light tree too deep");
+  int const rc = devAlloc(ctx, &ctx->d_lightTree, nodes.size());
+  if (rc) return rc;
+  if (!nodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_lightTree, nodes.data(), nodes.size() * sizeof(LightTreeNode), hipMemcpyHostToDevice));
+  ctx->lightTreeNodes = uint32_t(nodes.size());
+  ctx->lightTreeValid = true;
   return DMT_OK;
 }
 
@@ -1709,6 +1794,7 @@ int dmt_ctx_destroy(dmt_ctx* ctx) {
   (void)hipFree(ctx->d_bvhNodes);
   (void)hipFree(ctx->d_trisBvh);
   (void)hipFree(ctx->d_overflow);
+  (void)hipFree(ctx->d_lightTree);
   (void)hipFree(ctx->d_texRgba);
   (void)hipFree(ctx->d_texDesc);
   (void)hipFree(ctx->d_matTex);
@@ -1804,6 +1890,8 @@ int dmt_upload_lights(dmt_ctx* ctx, const void* lights32, uint32_t count, const 
   ctx->lightCount = count;
   ctx->infCount = infinite_count;
   ctx->haveLights = true;
+  ctx->h_lights.assign(static_cast<uint8_t const*>(lights32), static_cast<uint8_t const*>(lights32) + size_t(count) * 32);
+  ctx->lightTreeValid = false;
   return DMT_OK;
 }
 
@@ -1853,6 +1941,31 @@ int dmt_set_accel(dmt_ctx* ctx, int mode) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return buildBvh(ctx);
   }
+  return DMT_OK;
+}
+
+int dmt_set_light_sampling(dmt_ctx* ctx, int mode) {
+  if (!ctx) return DMT_ERR_INVALID;
+  if (mode != DMT_LIGHTS_UNIFORM && mode != DMT_LIGHTS_TREE) return fail(ctx, DMT_ERR_INVALID, "dmt_set_light_sampling: unknown mode");
+  ctx->lightSampling = mode;
+  return DMT_OK;
+}
+
+// host only: the probability with which the light tree built from `lights32` picks each light at (p, n)
+int dmt_light_tree_pmfs(const void* lights32, uint32_t count, const float* p3, const float* n3, float* pmf_out, int* node_count,
+                        int* depth) {
+  if ((count && !lights32) || !p3 || !n3 || !pmf_out) return DMT_ERR_INVALID;
+  std::vector<light_tree::Item> items;
+  for (uint32_t i = 0; i < count; ++i) {
+    light_tree::Item it{};
+    if (!light_tree::itemOf(static_cast<uint8_t const*>(lights32) + 32 * size_t(i), i, [](uint16_t h) { return h2f_host(h); }, it)) return DMT_ERR_INVALID;
+    items.push_back(it);
+  }
+  int d = 0;
+  std::vector<LightTreeNode> const nodes = light_tree::build(items, &d);
+  light_tree::pmfs(nodes, p3, n3, pmf_out, count);
+  if (node_count) *node_count = int(nodes.size());
+  if (depth) *depth = d;
   return DMT_OK;
 }
 
@@ -2061,7 +2174,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   uint32_t const ownedTiles = P.numItems;
   // BVH launches run as the megakernel unless the wavefront form (wavefront.hpp) is asked for: on the measured scenes
   // the megakernel is faster (1 M triangles: 489 vs 378 Msamples/s), so "automatic" means megakernel
-  bool const wavefront = ctx->accel == DMT_ACCEL_BVH && ctx->bvhStrategy == 2 && ctx->texCount == 0;  // textures: megakernels only
+  bool const wavefront = ctx->accel == DMT_ACCEL_BVH && ctx->bvhStrategy == 2 && ctx->texCount == 0 && !useLightTree(ctx);  // textures / light tree: megakernels only
   {  // fewer owned tiles than ~4 per resident wave: schedule row bands of the tiles instead of whole tiles
     uint32_t const waves = uint32_t(ctx->cuCount) * uint32_t(blocksPerCuOf(ctx)) * 4u;
     P.subShift = ctx->subShift >= 0 ? uint32_t(ctx->subShift) : 0u;
@@ -2098,6 +2211,10 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
     if (ctx->matTexCount != ctx->bsdfCount || ctx->triUvCount != ctx->triCount)
       return fail(ctx, DMT_ERR_STATE, "dmt_render: texture tables do not match the uploaded BSDFs / triangles (upload textures last)");
     P.texRgba = ctx->d_texRgba, P.texDesc = ctx->d_texDesc, P.matTex = ctx->d_matTex, P.triUv = ctx->d_triUv;
+  }
+  if (useLightTree(ctx)) {
+    if (int const rcT = ensureLightTree(ctx)) return rcT;
+    P.lightTree = ctx->d_lightTree;
   }
   uint32_t const blocksNeeded = (wavesWanted + 3) / 4;
   if (blocks > blocksNeeded) blocks = blocksNeeded;

@@ -90,6 +90,17 @@ int dmt_set_camera(dmt_ctx* ctx, const dmt_camera* cam);
 /* depth cap of the bounce loop; the reference hard-codes 32 (megakernel.cu:154) */
 int dmt_set_limits(dmt_ctx* ctx, int max_depth);
 int dmt_set_accel(dmt_ctx* ctx, int mode);
+/* SURVEY 8f-4 -- how next-event estimation picks its light from the uploaded light list.  DMT_LIGHTS_UNIFORM (default) is
+ * the reference megakernel's uniform pick (T/megakernel/megakernel.cu:170-173): the parity mode.  DMT_LIGHTS_TREE builds a
+ * light BVH over the point / spot lights (after src/core/public/core-light-tree-builder.h:17-110; differences and why in
+ * csrc/light_tree.hpp) and picks in proportion to flux x cosine / distance^2: same expected image, less noise with many
+ * lights.  Applies to plain light lists (scenes with emissive triangles or image textures keep the uniform pick). */
+#define DMT_LIGHTS_UNIFORM 0
+#define DMT_LIGHTS_TREE 1
+int dmt_set_light_sampling(dmt_ctx* ctx, int mode);
+/* host only (no GPU): probability of each of the `count` packed lights at point p3 with normal n3 under the tree */
+int dmt_light_tree_pmfs(const void* lights32, uint32_t count, const float* p3, const float* n3, float* pmf_out, int* node_count,
+                        int* depth);
 /* How DMT_ACCEL_BVH launches are executed (results are bit-identical either way): 0 = automatic = 1 = the megakernel
  * (fastest on every measured scene); 2 = the device-side wavefront -- generate / trace / shade / fold kernels over
  * path-state arrays in HBM, csrc/wavefront.hpp -- kept as a measured alternative.  paths_per_pass: path

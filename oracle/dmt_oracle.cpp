@@ -31,6 +31,7 @@
 // right-to-left (what g++ does, hence what produced the survey anchors); the default is
 // left-to-right (clang / nvcc front ends), which is what the HIP kernel implements.
 // =====================================================================================
+#include <algorithm>
 #include <atomic>
 #include <cfloat>
 #include <cmath>
@@ -1539,6 +1540,7 @@ struct Camera {  // CC/public/cuda-core/types.cuh:101-109 (44 bytes)
 };
 static_assert(sizeof(Camera) == 44, "DeviceCamera layout");
 
+struct LtNode;
 struct Scene {
   float const* xs;  // float4 per triangle
   float const* ys;
@@ -1566,6 +1568,8 @@ struct Scene {
   uint32_t texCount = 0;
   uint32_t const* matTex = nullptr;
   float const* triUv = nullptr;
+  // light tree (see "light tree" below); null = the megakernel's uniform pick
+  LtNode const* lightTree = nullptr;
 };
 
 struct Stats {  // algorithmic work counters (SURVEY 8d byte model)
@@ -1642,6 +1646,153 @@ inline float areaPdf(Scene const& sc, uint32_t tri, V3 rayD, float t) {
 }
 
 // one path; returns radiance L                                      megakernel.cu:103-297
+// ---- light tree ------------------------------------------------------------------------------------
+// Restates src/core/private/core-light-tree-builder.cpp (LightBounds :52-70, lbImportance :98-146, split cost :246-263,
+// selection :496-539, per-light probability :541-557) with the differences the product documents in csrc/light_tree.hpp:
+// every light omnidirectional (the megakernel's spot cone does not attenuate), one light per bounce, splits found by a
+// sorted sweep over the node's own lights, bounding-sphere test on |centre - p|^2.  No reference-side vectors: unpinned.
+struct LtNode {
+  float lo[3];
+  float phi;
+  float hi[3];
+  uint32_t ref;  // leaf: 0x80000000 | light; inner: left child (right = left + 1)
+};
+struct LtItem {
+  V3 pos;
+  float radius, phi;
+  uint32_t index;
+};
+inline float ltImportance(LtNode const& nd, V3 p, V3 n) {
+  V3 const c = v3(0.5f * (nd.lo[0] + nd.hi[0]), 0.5f * (nd.lo[1] + nd.hi[1]), 0.5f * (nd.lo[2] + nd.hi[2]));
+  V3 const dg = v3(nd.hi[0] - nd.lo[0], nd.hi[1] - nd.lo[1], nd.hi[2] - nd.lo[2]);
+  float const halfDiag = 0.5f * sqrtf(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z);
+  V3 const w = p - c;
+  float const d2 = w.x * w.x + w.y * w.y + w.z * w.z;
+  float const distSqr = fmaxf(d2, halfDiag);
+  float sinB = 0.f, cosB = -1.f;
+  if (d2 >= halfDiag * halfDiag && d2 > 0.f) {
+    float const s2 = (halfDiag * halfDiag) / d2;
+    sinB = sqrtf(s2), cosB = sqrtf(fmaxf(0.f, 1.f - s2));
+  }
+  float cosI = 1.f;
+  if (d2 > 0.f) cosI = fabsf((w.x * n.x + w.y * n.y + w.z * n.z) * (1.f / sqrtf(d2)));
+  float const sinI = sqrtf(fmaxf(0.f, 1.f - cosI * cosI));
+  float const cosIB = cosI > cosB ? 1.f : cosI * cosB + sinI * sinB;
+  return fmaxf(nd.phi * cosIB / distSqr, 0.f);
+}
+inline int ltSelect(LtNode const* nodes, V3 p, V3 n, float u, float* pmf) {
+  uint32_t at = 0;
+  *pmf = 1.f;
+  for (int guard = 0; guard < 64; ++guard) {
+    LtNode const& nd = nodes[at];
+    if (nd.ref & 0x80000000u) return int(nd.ref & 0x7FFFFFFFu);
+    float const i0 = ltImportance(nodes[nd.ref], p, n), i1 = ltImportance(nodes[nd.ref + 1u], p, n);
+    float const sum = i0 + i1;
+    if (!(sum > 0.f)) return -1;
+    float const p0 = i0 / sum;
+    if (u < p0) {
+      *pmf *= p0;
+      u = fminf(u / p0, 0.99999994f);
+      at = nd.ref;
+    } else {
+      *pmf *= 1.f - p0;
+      u = fminf((u - p0) / (1.f - p0), 0.99999994f);
+      at = nd.ref + 1u;
+    }
+  }
+  return -1;
+}
+inline void ltBounds(std::vector<LtItem> const& it, size_t a, size_t b, float lo[3], float hi[3], float* phi) {
+  *phi = 0.f;
+  for (int k = 0; k < 3; ++k) lo[k] = std::numeric_limits<float>::infinity(), hi[k] = -std::numeric_limits<float>::infinity();
+  for (size_t i = a; i < b; ++i) {
+    float const q[3] = {it[i].pos.x, it[i].pos.y, it[i].pos.z};
+    for (int k = 0; k < 3; ++k) lo[k] = std::min(lo[k], q[k] - it[i].radius), hi[k] = std::max(hi[k], q[k] + it[i].radius);
+    *phi += it[i].phi;
+  }
+}
+inline double ltArea(float const lo[3], float const hi[3]) {
+  double const dx = double(hi[0]) - lo[0], dy = double(hi[1]) - lo[1], dz = double(hi[2]) - lo[2];
+  return 2.0 * (dx * dy + dy * dz + dz * dx);
+}
+inline std::vector<LtNode> ltBuild(Rec32 const* lights, uint32_t count) {
+  std::vector<LtItem> items;
+  for (uint32_t i = 0; i < count; ++i) {
+    uint16_t const type = rd16(lights[i], L_TYPE);
+    if (type != LT_POINT && type != LT_SPOT) continue;
+    V3 const c = rdh3(lights[i], L_INT);
+    LtItem it;
+    it.pos = rdf3(lights[i], LP_POS);
+    it.radius = fmaxf(h2f(rd16(lights[i], type == LT_POINT ? LP_RAD : LS_RAD)), 0.f);
+    it.phi = 4.f * 3.14159265358979323846f * fmaxf(0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z, 0.f);
+    it.index = i;
+    items.push_back(it);
+  }
+  std::vector<LtNode> nodes;
+  if (items.empty()) return nodes;
+  struct Work {
+    uint32_t node;
+    size_t a, b;
+  };
+  nodes.emplace_back();
+  std::vector<Work> stack{{0u, 0, items.size()}};
+  while (!stack.empty()) {
+    Work const w = stack.back();
+    stack.pop_back();
+    LtNode nd{};
+    ltBounds(items, w.a, w.b, nd.lo, nd.hi, &nd.phi);
+    if (w.b - w.a == 1) {
+      nd.ref = 0x80000000u | items[w.a].index;
+      nodes[w.node] = nd;
+      continue;
+    }
+    int axis = 0;
+    for (int k = 1; k < 3; ++k)
+      if (nd.hi[k] - nd.lo[k] > nd.hi[axis] - nd.lo[axis]) axis = k;
+    auto coord = [axis](LtItem const& x) { return axis == 0 ? x.pos.x : (axis == 1 ? x.pos.y : x.pos.z); };
+    std::stable_sort(items.begin() + long(w.a), items.begin() + long(w.b), [&](LtItem const& x, LtItem const& y) {
+      return coord(x) < coord(y) || (coord(x) == coord(y) && x.index < y.index);
+    });
+    size_t const n = w.b - w.a;
+    size_t best = n / 2;
+    double bestCost = std::numeric_limits<double>::infinity();
+    for (size_t k = 1; k < n; ++k) {
+      float lo[3], hi[3], phiL, phiR;
+      ltBounds(items, w.a, w.a + k, lo, hi, &phiL);
+      double const cl = double(phiL) * ltArea(lo, hi);
+      ltBounds(items, w.a + k, w.b, lo, hi, &phiR);
+      double const cost = cl + double(phiR) * ltArea(lo, hi);
+      if (cost < bestCost * (1.0 - 1e-9)) bestCost = cost, best = k;
+    }
+    uint32_t const left = uint32_t(nodes.size());
+    nodes.emplace_back(), nodes.emplace_back();
+    nd.ref = left;
+    nodes[w.node] = nd;
+    stack.push_back({left + 1u, w.a + best, w.b});
+    stack.push_back({left, w.a, w.a + best});
+  }
+  return nodes;
+}
+inline void ltPmfs(std::vector<LtNode> const& nodes, V3 p, V3 n, float* out, uint32_t count) {
+  for (uint32_t i = 0; i < count; ++i) out[i] = 0.f;
+  if (nodes.empty()) return;
+  std::vector<std::pair<uint32_t, float>> stack{{0u, 1.f}};
+  while (!stack.empty()) {
+    auto const w = stack.back();
+    stack.pop_back();
+    LtNode const& nd = nodes[w.first];
+    if (nd.ref & 0x80000000u) {
+      if ((nd.ref & 0x7FFFFFFFu) < count) out[nd.ref & 0x7FFFFFFFu] = w.second;
+      continue;
+    }
+    float const i0 = ltImportance(nodes[nd.ref], p, n), i1 = ltImportance(nodes[nd.ref + 1u], p, n);
+    if (!(i0 + i1 > 0.f)) continue;
+    float const p0 = i0 / (i0 + i1);
+    stack.push_back({nd.ref, w.second * p0});
+    stack.push_back({nd.ref + 1u, w.second * (1.f - p0)});
+  }
+}
+
 // ---- image textures ------------------------------------------------------------------------------
 // One texel: mirror wrap (the only mode the reference's material code asks for, core-material.cpp:114-116), byte / 255
 // (core-texture.cu readRGB of ByteRGB).  core-texture.cu:895-915.
@@ -1854,11 +2005,19 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
         }
       }
     } else if (sc.lightCount > 0) {
-      uint32_t const li = sc.areaCount > 0 ? pickIndex(uLight, sc.lightCount + sc.areaCount) : pickIndex(uLight, sc.lightCount);
+      uint32_t li = sc.areaCount > 0 ? pickIndex(uLight, sc.lightCount + sc.areaCount) : pickIndex(uLight, sc.lightCount);
+      float lightPMF = (sc.env ? 0.5f : 1.f) / float(sc.lightCount + sc.areaCount);
+      bool picked = true;
+      if (sc.lightTree && sc.lightCount > 1 && sc.areaCount == 0 && !sc.matTex) {  // same applicability rule as the product
+        float treePmf = 0.f;
+        int const sel = ltSelect(sc.lightTree, hit.pos, hit.normal, uLight, &treePmf);
+        picked = sel >= 0;
+        li = picked ? uint32_t(sel) : 0u;
+        lightPMF = (sc.env ? 0.5f : 1.f) * treePmf;
+      }
       Rec32 const& light = sc.lights[li];
-      float const lightPMF = (sc.env ? 0.5f : 1.f) / float(sc.lightCount + sc.areaCount);
       LightSample const ls = sampleLight(light, hit.pos, uLight2, lastBounceTransmission, hit.normal);
-      if (ls.valid()) {
+      if (picked && ls.valid()) {
         Ray const shadow{offsetRayOrigin(hit.pos, hit.error, hit.normal, ls.direction), ls.direction};
         bool doNEE = true;
         if (st) st->shadowRays++;
@@ -2097,9 +2256,11 @@ struct OracleScene {  // mirrors include/dmt_hip.h's upload calls
   uint32_t texCount;
   const uint32_t* matTex;
   const float* triUv;
+  int32_t lightSampling;  // 0 = uniform pick, 1 = light tree
 };
 
-static Scene toScene(OracleScene const* s, EnvMap* envStorage = nullptr, std::vector<uint32_t>* areaStorage = nullptr) {
+static Scene toScene(OracleScene const* s, EnvMap* envStorage = nullptr, std::vector<uint32_t>* areaStorage = nullptr,
+                     std::vector<LtNode>* treeStorage = nullptr) {
   Scene sc;
   if (areaStorage && s->areaCount > 0 && s->areaTri && s->areaLe) {
     areaStorage->assign(size_t(s->triCount), 0xFFFFFFFFu);
@@ -2117,7 +2278,19 @@ static Scene toScene(OracleScene const* s, EnvMap* envStorage = nullptr, std::ve
   sc.bsdfs = reinterpret_cast<Rec32 const*>(s->bsdfs), sc.bsdfCount = s->bsdfCount;
   if (s->texCount > 0 && s->texRgba && s->texDesc && s->matTex && s->triUv)
     sc.texRgba = s->texRgba, sc.texDesc = s->texDesc, sc.texCount = s->texCount, sc.matTex = s->matTex, sc.triUv = s->triUv;
+  if (treeStorage && s->lightSampling == 1 && s->lightCount > 1) {
+    *treeStorage = ltBuild(sc.lights, sc.lightCount);
+    if (!treeStorage->empty()) sc.lightTree = treeStorage->data();
+  }
   return sc;
+}
+
+// per-light selection probability at (p, n) of the tree over `count` packed lights; also node count and depth-free checks
+int oracle_light_tree_pmfs(const void* lights32, uint32_t count, const float* p3, const float* n3, float* out, int* nodeCount) {
+  std::vector<LtNode> const nodes = ltBuild(reinterpret_cast<Rec32 const*>(lights32), count);
+  ltPmfs(nodes, v3(p3[0], p3[1], p3[2]), v3(n3[0], n3[1], n3[2]), out, count);
+  if (nodeCount) *nodeCount = int(nodes.size());
+  return 0;
 }
 
 // --- scene: cornellBox() -----------------------------------------------------------------
@@ -2340,7 +2513,8 @@ int oracle_render(const OracleScene* s, const void* camera44, int maxDepth, int 
   memcpy(&cam, camera44, sizeof(Camera));
   EnvMap env;
   std::vector<uint32_t> areaOf;
-  Scene const sc = toScene(s, &env, &areaOf);
+  std::vector<LtNode> lightTree;
+  Scene const sc = toScene(s, &env, &areaOf, &lightTree);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   if (x0 < 0) x0 = 0;
   if (y0 < 0) y0 = 0;
@@ -2391,7 +2565,8 @@ void oracle_trace_samples(const OracleScene* s, const void* camera44, int maxDep
   memcpy(&cam, camera44, sizeof(Camera));
   EnvMap env;
   std::vector<uint32_t> areaOf;
-  Scene const sc = toScene(s, &env, &areaOf);
+  std::vector<LtNode> lightTree;
+  Scene const sc = toScene(s, &env, &areaOf, &lightTree);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   for (int i = 0; i < n; ++i) {
     V3 const L = tracePath(sc, cfg, pxs[i], pys[i], ss[i], nullptr);
@@ -2406,7 +2581,8 @@ int oracle_trace_log(const OracleScene* s, const void* camera44, int maxDepth, i
   memcpy(&cam, camera44, sizeof(Camera));
   EnvMap env;
   std::vector<uint32_t> areaOf;
-  Scene const sc = toScene(s, &env, &areaOf);
+  std::vector<LtNode> lightTree;
+  Scene const sc = toScene(s, &env, &areaOf, &lightTree);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   PathLog log;
   log.rec = rec12, log.cap = cap;

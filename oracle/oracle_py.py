@@ -31,6 +31,7 @@ class OracleScene(C.Structure):
         ("envScale", C.c_float),
         ("areaTri", C.c_void_p), ("areaLe", C.c_void_p), ("areaCount", C.c_uint32),
         ("texRgba", C.c_void_p), ("texDesc", C.c_void_p), ("texCount", C.c_uint32), ("matTex", C.c_void_p), ("triUv", C.c_void_p),
+        ("lightSampling", C.c_int32),
     ]
 
 
@@ -124,6 +125,7 @@ class Scene:
             s.envScale = self.env_scale
         if self.area_tri is not None and self.area_tri.shape[0] > 0:
             s.areaTri, s.areaLe, s.areaCount = _p(self.area_tri), _p(self.area_le), self.area_tri.shape[0]
+        s.lightSampling = int(getattr(self, "light_sampling", 0))
         if getattr(self, "tex_desc", None) is not None and len(self.tex_desc) > 0:
             s.texRgba, s.texDesc, s.texCount = _p(self.tex_rgba), _p(self.tex_desc), self.tex_desc.shape[0]
             s.matTex, s.triUv = _p(self.mat_tex), _p(self.tri_uv)
@@ -395,3 +397,14 @@ def trace_log(scene, px, py, s, max_depth=32, rtl_args=False, cap=64):
     n = lib().oracle_trace_log(C.byref(cs), _p(scene.camera), int(max_depth), int(px), int(py), int(s),
                                int(bool(rtl_args)), _p(rec), int(cap), _p(L))
     return rec[:n], L
+
+
+def light_tree_pmfs(lights32, p, n):
+    """selection probability of every packed light at point p with normal n under the oracle's own tree."""
+    L = np.ascontiguousarray(lights32, np.uint8).reshape(-1, 32)
+    out = np.zeros(L.shape[0], np.float32)
+    nc = C.c_int()
+    lib().oracle_light_tree_pmfs(_p(L), C.c_uint32(L.shape[0]), _p(np.ascontiguousarray(p, np.float32)),
+                                 _p(np.ascontiguousarray(n, np.float32)), _p(out), C.byref(nc))
+    return out, nc.value
+

@@ -1043,3 +1043,81 @@ def test_texture_upload_is_validated(renderer, pkg, O):
     renderer.render(1)                                           # cleared: plain kernels again
     renderer.sync()
 
+
+# ---------------------------------------------------------------------------------------------
+# light tree (opt-in; the uniform pick stays the parity mode).  Parity unpinned: oracle <-> HIP only.
+# ---------------------------------------------------------------------------------------------
+def _many_lights_cornell(O, pkg, res, nlights=48, env=False):
+    from test_light_tree import _lights
+    sc = O.cornell_box(res, res)
+    # radius 2e-4: "effectively delta" lights (radius / distance < 1e-3, light.cu:29,131), the kind the JSON front-end
+    # makes.  For those NEE is Le f / pmf and any selection probability gives the same expected image.  For larger
+    # lights the reference weights NEE by a power heuristic that is NOT divided by the light pdf (megakernel.cu:233-238,
+    # kept for parity): its expectation depends on the selection probabilities, so there the tree changes the picture.
+    L = _lights(pkg, nlights, 11, spread=0.9, radius=2e-4)
+    pos = L[:, 8:20].copy().view(np.float32).reshape(-1, 3)
+    pos[:] = pos * [1.0, 0.25, 0.9] + [0.0, 0.5, 0.6]             # inside the box (y 1..3, z -0.3..1.5), near the ceiling
+    L[:, 8:20] = pos.view(np.uint8).reshape(-1, 12)
+    sc.lights = L
+    if env:
+        sc.set_envmap(pkg.host_scene.synthetic_sky(16))
+    return sc
+
+
+@pytest.mark.parametrize("accel, env", [(0, False), (1, False), (1, True)])
+def test_light_tree_film_vs_oracle(renderer, pkg, O, accel, env):
+    sc = _many_lights_cornell(O, pkg, 64, env=env)
+    sc.light_sampling = 1
+    renderer.upload_scene(sc)
+    renderer.set_limits(5)
+    renderer.set_accel(accel)
+    renderer.set_partition(0, 1)
+    renderer.set_light_sampling(1)
+    try:
+        renderer.film_clear()
+        renderer.render(32)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
+        renderer.set_light_sampling(0)
+        renderer.film_clear()
+        renderer.render(32)
+        renderer.sync()
+        umean, um2 = renderer.download_film()
+    finally:
+        renderer.set_light_sampling(0)
+        renderer.set_accel(0)
+        renderer.clear_envmap()
+    om, om2 = O.render(sc, 32, max_depth=5, threads=8)[:2]
+    assert np.array_equal(m2[..., 3], om2[..., 3]) and np.isfinite(mean).all()
+    scale = float(om[..., :3].mean())
+    assert film_rmse(mean, om) < RMSE_TOL * max(1.0, scale), film_rmse(mean, om)
+    # same expected image as the uniform pick (both unbiased): the 32-spp means agree within the noise of the noisier one ...
+    stderr_u = float((np.sqrt(np.maximum(um2[..., :3], 0)) / 32).mean())
+    assert abs(float(mean[..., :3].mean()) - float(umean[..., :3].mean())) < 0.05 * scale
+    # ... and the tree has clearly less variance with 48 lights of very different flux and distance
+    assert float(m2[..., :3].mean()) < 0.6 * float(um2[..., :3].mean()), (float(m2[..., :3].mean()), float(um2[..., :3].mean()), stderr_u)
+
+
+def test_light_tree_converges_to_the_uniform_image(renderer, pkg, O):
+    """Unbiasedness on the GPU: 2 048 spp with the tree vs 2 048 spp with the uniform pick, 48 x 48 pixels."""
+    sc = _many_lights_cornell(O, pkg, 48)
+    renderer.upload_scene(sc)
+    renderer.set_limits(4)
+    renderer.set_accel(0)
+    renderer.set_partition(0, 1)
+    films = []
+    try:
+        for mode in (0, 1):
+            renderer.set_light_sampling(mode)
+            renderer.film_clear()
+            renderer.render(2048)
+            renderer.sync()
+            films.append(renderer.download_film())
+    finally:
+        renderer.set_light_sampling(0)
+    (um, um2), (tm, tm2) = films
+    se = np.sqrt(np.maximum(um2[..., :3], 0)) / 2048 + np.sqrt(np.maximum(tm2[..., :3], 0)) / 2048   # standard errors of both means
+    z = np.abs(um[..., :3] - tm[..., :3]) / np.maximum(se, 1e-9)
+    assert np.percentile(z, 99) < 5.0 and z.mean() < 1.5, (float(np.percentile(z, 99)), float(z.mean()))
+    assert float(tm2[..., :3].mean()) < 0.6 * float(um2[..., :3].mean())
+
