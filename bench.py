@@ -328,9 +328,9 @@ def main():
                 if getattr(scene, "env_rgb", None) is not None:
                     oscene.set_envmap(scene.env_rgb, scene.env_quat, scene.env_scale)
                 threads = int(os.environ.get("DMT_CPU_THREADS", min(os.cpu_count() or 1, 16)))
-                # bounded sample: ~1e10 triangle tests (10-20 s on 16 host threads), from the GPU's own ray counters
+                # bounded sample: ~6e9 triangle tests (10-30 s on 16 host threads), from the GPU's own ray counters
                 rays = (stats["closest_rays"] + stats["shadow_rays"]) / max(1.0, stats["samples"])
-                want = max(16.0, 1e10 / max(1.0, rays * scene.tri_count))
+                want = max(16.0, 6e9 / max(1.0, rays * scene.tri_count))
                 ospp = int(min(spp, max(1, want // width)))
                 npx = int(min(width, max(16, want // ospp)))
                 nrows = int(min(height, max(1, round(want / (ospp * npx)))))
