@@ -1390,6 +1390,7 @@ struct dmt_ctx {
   uint32_t lightTreeNodes = 0;
   int lightTreeDepth = 0;
   bool lightTreeValid = false;
+  bool lightsTreeable = false;     // every record of the light list is a point or spot light
   std::vector<std::pair<void const*, int>> occupancy;  // megakernel variant -> resident 256-thread blocks per CU
   // SURVEY 8f-1 image textures (one allocation each)
   uint32_t* d_texRgba = nullptr;
@@ -1543,7 +1544,7 @@ SamplerParams computeSamplerParams(int width, int height) {
 
 // the light tree applies to plain point / spot light lists; textured or emissive-triangle scenes keep the uniform pick
 bool useLightTree(dmt_ctx const* c) {
-  return c->lightSampling == DMT_LIGHTS_TREE && c->lightCount > 1 && c->areaCount == 0 && c->texCount == 0;
+  return c->lightSampling == DMT_LIGHTS_TREE && c->lightCount > 1 && c->lightsTreeable && c->areaCount == 0 && c->texCount == 0;
 }
 int ensureLightTree(dmt_ctx* ctx);
 
@@ -1892,6 +1893,12 @@ int dmt_upload_lights(dmt_ctx* ctx, const void* lights32, uint32_t count, const 
   ctx->haveLights = true;
   ctx->h_lights.assign(static_cast<uint8_t const*>(lights32), static_cast<uint8_t const*>(lights32) + size_t(count) * 32);
   ctx->lightTreeValid = false;
+  ctx->lightsTreeable = count > 0;
+  for (uint32_t i = 0; i < count; ++i) {  // a directional light in the list (PBRT "distant") has no position: such lists keep the uniform pick
+    uint16_t type;
+    memcpy(&type, ctx->h_lights.data() + 32 * size_t(i) + 6, 2);
+    if (type != 0 && type != 1) ctx->lightsTreeable = false;
+  }
   return DMT_OK;
 }
 

@@ -94,7 +94,8 @@ int dmt_set_accel(dmt_ctx* ctx, int mode);
  * the reference megakernel's uniform pick (T/megakernel/megakernel.cu:170-173): the parity mode.  DMT_LIGHTS_TREE builds a
  * light BVH over the point / spot lights (after src/core/public/core-light-tree-builder.h:17-110; differences and why in
  * csrc/light_tree.hpp) and picks in proportion to flux x cosine / distance^2: same expected image, less noise with many
- * lights.  Applies to plain light lists (scenes with emissive triangles or image textures keep the uniform pick). */
+ * lights.  Applies to light lists of point / spot lights (scenes with emissive triangles, image textures, or a
+ * directional light in the list keep the uniform pick). */
 #define DMT_LIGHTS_UNIFORM 0
 #define DMT_LIGHTS_TREE 1
 int dmt_set_light_sampling(dmt_ctx* ctx, int mode);

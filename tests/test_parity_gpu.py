@@ -1121,3 +1121,43 @@ def test_light_tree_converges_to_the_uniform_image(renderer, pkg, O):
     assert np.percentile(z, 99) < 5.0 and z.mean() < 1.5, (float(np.percentile(z, 99)), float(z.mean()))
     assert float(tm2[..., :3].mean()) < 0.6 * float(um2[..., :3].mean())
 
+
+def test_light_tree_falls_back_where_it_does_not_apply(renderer, pkg, O):
+    """One light, a directional light in the list, emissive triangles: the uniform pick runs (bit-identical films)."""
+    import ctypes as C
+    H = pkg.host_scene.load_host_library()
+    f3 = lambda v: np.ascontiguousarray(v, np.float32).ctypes.data_as(C.c_void_p)
+    sc = O.cornell_box(40, 40)
+    distant = np.zeros(32, np.uint8)
+    H.dmt_host_make_directional_light(f3([0.4, 0.4, 0.3]), f3([0.2, 0.6, -0.7]), C.c_float(0.0), distant.ctypes.data_as(C.c_void_p))
+    cases = [sc.lights.copy(), np.concatenate([sc.lights, distant[None]])]
+    renderer.set_limits(5)
+    renderer.set_accel(0)
+    renderer.set_partition(0, 1)
+    try:
+        for lights in cases:
+            sc.lights = lights
+            renderer.upload_scene(sc)
+            films = []
+            for mode in (0, 1):
+                renderer.set_light_sampling(mode)
+                renderer.film_clear()
+                renderer.render(8)
+                renderer.sync()
+                films.append(renderer.download_film())
+            assert np.array_equal(films[0][0], films[1][0]) and np.array_equal(films[0][1], films[1][1])
+    finally:
+        renderer.set_light_sampling(0)
+
+
+def test_textures_and_area_lights_are_refused_together(renderer, pkg, O):
+    sc = _textured_cornell(O, pkg, 32)
+    sc.set_area_lights([20], [[5, 5, 5]])
+    renderer.upload_scene(sc)
+    try:
+        with pytest.raises(pkg.DmtError, match="not supported"):
+            renderer.render(1)
+    finally:
+        renderer.upload_textures(None, None, None, None)
+        renderer.upload_area_lights([], np.zeros((0, 3), np.float32))
+
