@@ -124,13 +124,16 @@ def load_pmc(workload, kspp):
         return None
 
 
-def build_roofline(workload, stats, avg_ms, samples_per_launch, kspp, pmc, info=None):
+def build_roofline(workload, stats, avg_ms, samples_per_launch, kspp, pmc, info=None, world=1):
     """The `roofline` object of the JSON line (pure function: exercised on CPU by tests/test_bench_contract.py).
     stats: per-workload work counters or None; pmc: load_pmc() record or None."""
     scene_kind = WORKLOADS[workload][4]
     use_bvh = scene_kind != "cornell"
     secs = avg_ms * 1e-3
+    # the PMC record is a 1-GPU launch over the whole frame; a rank of an N-GPU run renders (and moves) 1/N of it
     traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+    if traffic is not None and world > 1:
+        traffic = traffic / world
     hbm_view = None
     if traffic is not None and secs > 0:
         gbs = traffic / secs / 1e9
@@ -386,7 +389,7 @@ def main():
         roofline = None
         if launches > 0:
             roofline = build_roofline(args.workload, stats, kernel_ms / launches, float(width) * height * kspp / world, kspp,
-                                      load_pmc(args.workload, kspp), info)
+                                      load_pmc(args.workload, kspp), info, world)
             roofline["launches"] = int(launches)
 
         scene_text = {
