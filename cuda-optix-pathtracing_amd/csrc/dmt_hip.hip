@@ -114,6 +114,27 @@ DMT_DEV EnvView load_env(KArgs k) {
   return e;
 }
 
+// Diagnostic build only (make variant DEFS=-DDMT_SECTION_TIMING=1): wave-level shader-clock cycles spent in each section of
+// the brute-force megakernel, summed over all waves; read back with dmt_diag_section_cycles (tools/diag_sections.py).
+#ifndef DMT_SECTION_TIMING
+#define DMT_SECTION_TIMING 0
+#endif
+#if DMT_SECTION_TIMING
+__device__ unsigned long long g_sect[16];
+__shared__ unsigned long long s_sectLast[kLdsThreads / 64];
+__shared__ unsigned long long s_sectAcc[kLdsThreads / 64][16];
+#endif
+DMT_DEV void sect_mark(int i) {  // everything since the previous mark belongs to section i
+#if DMT_SECTION_TIMING
+  unsigned long long const now = __builtin_readcyclecounter();
+  unsigned long long const m = __ballot(1);
+  if (int(__ffsll((long long)m)) - 1 == int(threadIdx.x & 63u)) {
+    uint32_t const w = threadIdx.x >> 6;
+    s_sectAcc[w][i] += now - s_sectLast[w];
+    s_sectLast[w] = now;
+  }
+#endif
+}
 struct PathState {
   RayPair rp;       // .x = current path's ray, .y = pending shadow ray
   f3 beta, L;
@@ -321,6 +342,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
       float const pmf = 1.f / float(sc.infLightCount);
       if (light_type(light) == LT_ENV) st.L = st.L + st.beta * light_intensity(light) / pmf;
     }
+    sect_mark(4);
     return true;
   }
   f3 const rd = ray_dir(st);
@@ -344,13 +366,25 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
       }
     }
   }
+  sect_mark(4);
   if (st.depth >= maxDepth) return true;  // :154-158
 
   f3 const wo = -rd;
   Rec32 rec = sc.bsdfs[hit.matId];
   f3 ns = hit.normal;  // shading normal: the geometric one unless a normal map says otherwise
   if constexpr (TEX) ns = apply_material_textures(k, rec, hit.matId, bestTri, bu, bv, hit.normal);
+#if DMT_SECTION_TIMING
+  {  // material mix of the lanes that shade in this pass: [11] passes with a GGX lane, [12] GGX lanes, [13] passes, [14] lanes
+    bool const ggx = hi16(rec.w[1]) != BS_OREN;
+    unsigned long long const all = __ballot(1), mg = __ballot(ggx);
+    if (int(__ffsll((long long)all)) - 1 == int(threadIdx.x & 63u)) {
+      unsigned long long* const acc = s_sectAcc[threadIdx.x >> 6];
+      acc[11] += mg ? 1u : 0u, acc[12] += uint32_t(__popcll(mg)), acc[13] += 1u, acc[14] += uint32_t(__popcll(all));
+    }
+  }
+#endif
   Bsdf const b = bsdf_prepare(rec, ns, wo);  // :165-166
+  sect_mark(5);
 
   // next-event estimation (:170-241)
   float uLight = st.rng.get1D();
@@ -413,6 +447,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
     }
     Rec32 const light = sc.lights[li];
     LightSample const ls = sample_light(light, hit.pos, uLight2, st.lastT, hit.normal);
+    sect_mark(6);
     if (picked && ls.valid()) {
       float bsdfPdf = 0.f;
       f3 const f = eval_bsdf(b, wo, ls.direction, ns, hit.normal, bsdfPdf) * b.weight;
@@ -433,9 +468,11 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
   }
 
   // bounce (:247-295); get2D before get1D = left-to-right argument evaluation
+  sect_mark(7);
   f2 const u2 = st.rng.get2D();
   float const uc = st.rng.get1D();
   BsdfSample const bs = sample_bsdf(b, wo, ns, hit.normal, u2, uc);
+  sect_mark(8);
   if (!bs.valid()) return true;
   st.lastT = bs.refract;
   if constexpr (ENV || AREA) st.lastPdf = bs.pdf, st.lastSpecular = bs.delta;
@@ -448,6 +485,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
     st.beta = st.beta / (1 - q);
   }
   ++st.depth;
+  sect_mark(9);
   return false;
 }
 
@@ -551,6 +589,7 @@ DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneS
     trace_pair_bvh<STATS>(k, st, doC, doS, gtid, bestTri, bu, bv, occluded, ls);
   else
     trace_pair_brute(k, st, doC, doS, bestTri, bu, bv, occluded);
+  sect_mark(2);
   if constexpr (STATS) ls->bounces += (doC && bestTri >= 0 && st.depth < kargs(k)->maxDepth) ? 1u : 0u;
   lane_finish<ENV, AREA, TEX, LTREE>(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
 }
@@ -570,6 +609,7 @@ DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri
       st.L = st.L + get_C();  // NEE of the previous bounce, added before anything of this bounce
     }
   }
+  sect_mark(3);
   if (doC) {
     if (path_shade<ENV, AREA, TEX, LTREE>(k, st, bestTri, bu, bv)) {
       st.active = false;
@@ -582,6 +622,7 @@ DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri
       }
     }
   }
+  sect_mark(10);
 }
 
 // the lane's NEXT sample, prepared ahead of need (sampler values + camera ray), [field][thread]
@@ -928,6 +969,10 @@ DMT_DEV void megakernel_body() {
   LaneSched Ls;
   PathState st{};
   auto sink = [&](f3 L, uint32_t sidx) { stage_sample(Pk, gtid, sidx, L); };
+#if DMT_SECTION_TIMING
+  if (lane < 16) s_sectAcc[threadIdx.x >> 6][lane] = 0;
+  sect_mark(15);
+#endif
   if (sched_begin(Pk, lane, W)) {
     for (;;) {
       bool const needPrep = !Ls.prepared;
@@ -938,20 +983,27 @@ DMT_DEV void megakernel_body() {
         Ls.prepared = false;
         if constexpr (STATS) ++ls.samples;
       }
+      sect_mark(0);
       if (W.alloc != W.cur || W.nextUnit == W.totalUnits) {  // item cur has no units left: is it complete?
         if (!__any(lane_holds(st, Ls, (W.cur & 1u) != 0u))) {
           // fold it now if the tile's previous chunk is in the film; otherwise keep tracing the other item
           // meanwhile (matters when a GPU has fewer tiles than resident waves: 1/8 of a 1024^2 frame)
           bool const busy = __any(st.active || st.hasShadow);
           if (!busy || fold_ready(Pk, lane, W.cur)) {
-            if (!sched_retire(Pk, gtid, lane, W)) break;
+            bool const more = sched_retire(Pk, gtid, lane, W);
+            sect_mark(1);
+            if (!more) break;
             continue;
           }
         }
       }
+      sect_mark(1);
       lane_step<BVH, STATS, ENV, AREA, TEX, LTREE>(Pk, gtid, st, sink, STATS ? &ls : nullptr);
     }
   }
+#if DMT_SECTION_TIMING
+  if (lane < 16) atomicAdd(&g_sect[lane], s_sectAcc[threadIdx.x >> 6][lane]);
+#endif
   flush_stats<STATS>(Pk, ls);
 }
 
@@ -2282,6 +2334,18 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   ++ctx->eventsUsed;
   return DMT_OK;
 }
+
+#if DMT_SECTION_TIMING
+extern "C" int dmt_diag_section_cycles(unsigned long long* out16, int reset) {
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sect), 16 * sizeof(unsigned long long));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[16] = {};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_sect), z, sizeof(z));
+  }
+  return e == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Host-only: build the BVH of a soup and check its invariants (every triangle in exactly one leaf, every DECODED
 // (quantised) child box encloses all vertices below it and lies inside its parent's decoded box up to one quantisation

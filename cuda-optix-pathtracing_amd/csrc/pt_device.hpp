@@ -235,6 +235,14 @@ DMT_DEV uint32_t mix_bits32(uint32_t v) {  // rng.cu:61-68
   v ^= v >> 16;
   return v;
 }
+// x - q * BASE for the TRUE quotient q = x / BASE.  The result is a digit (< 32), so only its low bits are needed and one
+// multiply-add supplies them whatever the compiler makes of the constant division: (q mod 2^24) * (2^24 - BASE) + x has the
+// low 24 bits of x - q * BASE.  (Integer multiplies issue at the full VALU rate on gfx950 -- tools/ubench/intops.hip -- so
+// the sampler's cost is its instruction COUNT; this form is one instruction where the compiler otherwise emits two or three.)
+template <uint32_t BASE>
+DMT_DEV uint32_t digit_of(uint32_t x, uint32_t q) {
+  return ((q & 0xFFFFFFu) * (0x1000000u - BASE) + x) & 0xFFu;
+}
 template <uint32_t BASE>
 DMT_DEV float owen_radical_inverse(uint32_t index, uint32_t seed) {  // rng.cu:137-173
   float const invBase = 1.0f / float(BASE);  // correctly rounded at compile time (= __frcp_rn)
@@ -243,9 +251,10 @@ DMT_DEV float owen_radical_inverse(uint32_t index, uint32_t seed) {  // rng.cu:1
   uint32_t revHash = 0;
   while (index > 0) {
     uint32_t const next = index / BASE;
-    uint32_t const digit = index - next * BASE;
+    uint32_t const digit = digit_of<BASE>(index, next);
     uint32_t const scramble = mix_bits32(seed ^ revHash);
-    uint32_t const permuted = (digit + scramble) % BASE;  // 32-bit wraparound, as the reference
+    uint32_t const sum = digit + scramble;  // 32-bit wraparound, as the reference
+    uint32_t const permuted = digit_of<BASE>(sum, sum / BASE);
     result = __builtin_fmaf(float(permuted), invBasePow, result);
     revHash = revHash * BASE + digit;
     invBasePow *= invBase;
