@@ -243,22 +243,102 @@ template <uint32_t BASE>
 DMT_DEV uint32_t digit_of(uint32_t x, uint32_t q) {
   return ((q & 0xFFFFFFu) * (0x1000000u - BASE) + x) & 0xFFu;
 }
+// Permutation tables for the first three digits of every dimension.  The Owen scramble of a digit hashes the digits
+// BELOW it, so for digit positions 0, 1, 2 the hash input takes 1, BASE, BASE^2 values: the table holds
+// mix_bits32(seed ^ prefix) % BASE for each of them (124 + 2 384 bytes for the eight dimensions), and the permuted digit
+// (digit + scramble) % BASE becomes an add and a conditional subtract instead of the two-multiply hash and a division.
+// Exact only while digit + scramble does not wrap at 2^32, which `exact` checks for every entry at compile time.
+constexpr uint32_t mix_bits32_c(uint32_t v) {
+  v ^= v >> 16;
+  v *= 0x7feb352dU;
+  v ^= v >> 15;
+  v *= 0x846ca68bU;
+  v ^= v >> 16;
+  return v;
+}
+constexpr uint32_t kOwenBases[8] = {5, 7, 11, 13, 17, 19, 23, 29};  // dimensions 2..9 (rng.cu:175-178 via sampler_values)
+constexpr uint32_t owen_seed(int dim) { return mix_bits32_c(1u + (uint32_t(dim) << 4)); }
+constexpr uint32_t owen_table1_offset(int dim) {
+  uint32_t at = 0;
+  for (int i = 0; i < dim - 2; ++i) at += kOwenBases[i];
+  return at;
+}
+constexpr uint32_t owen_table2_offset(int dim) {
+  uint32_t at = 124;
+  for (int i = 0; i < dim - 2; ++i) at += kOwenBases[i] * kOwenBases[i];
+  return at;
+}
+constexpr uint32_t kOwenTableBytes = 124 + 2384;
+struct OwenTables {
+  uint8_t t[kOwenTableBytes];
+  bool exact;
+};
+constexpr OwenTables make_owen_tables() {
+  OwenTables T{};
+  T.exact = true;
+  for (int dim = 2; dim < 10; ++dim) {
+    uint32_t const base = kOwenBases[dim - 2], seed = owen_seed(dim);
+    if (mix_bits32_c(seed) > 0xFFFFFFFFu - (base - 1u)) T.exact = false;  // position 0 (a constant, see sample_dim)
+    for (uint32_t prefix = 0; prefix < base; ++prefix) {
+      uint32_t const sc = mix_bits32_c(seed ^ prefix);
+      if (sc > 0xFFFFFFFFu - (base - 1u)) T.exact = false;
+      T.t[owen_table1_offset(dim) + prefix] = uint8_t(sc % base);
+    }
+    for (uint32_t prefix = 0; prefix < base * base; ++prefix) {
+      uint32_t const sc = mix_bits32_c(seed ^ prefix);
+      if (sc > 0xFFFFFFFFu - (base - 1u)) T.exact = false;
+      T.t[owen_table2_offset(dim) + prefix] = uint8_t(sc % base);
+    }
+  }
+  return T;
+}
+static_assert(owen_table2_offset(10) == kOwenTableBytes, "table size");
+static_assert(make_owen_tables().exact, "a scramble within BASE of 2^32: that prefix needs the wrapping sum");
+__constant__ OwenTables c_owen = make_owen_tables();
+
 template <uint32_t BASE>
-DMT_DEV float owen_radical_inverse(uint32_t index, uint32_t seed) {  // rng.cu:137-173
+DMT_DEV uint32_t add_mod(uint32_t digit, uint32_t scrambleModBase) {  // (digit + s) % BASE for digit, s < BASE
+  uint32_t const t = digit + scrambleModBase;
+  uint32_t const w = t - BASE;  // wraps to a huge value when t < BASE
+  return t < w ? t : w;
+}
+template <int DIM, uint32_t BASE>
+DMT_DEV float sample_dim(uint32_t index) {  // owenScrambledRadicalInverse, rng.cu:137-178
+  static_assert(kOwenBases[DIM - 2] == BASE, "dimension / base");
+  constexpr uint32_t seed = owen_seed(DIM);
   float const invBase = 1.0f / float(BASE);  // correctly rounded at compile time (= __frcp_rn)
   float result = 0.0f;
-  float invBasePow = invBase;
-  uint32_t revHash = 0;
-  while (index > 0) {
-    uint32_t const next = index / BASE;
-    uint32_t const digit = digit_of<BASE>(index, next);
-    uint32_t const scramble = mix_bits32(seed ^ revHash);
-    uint32_t const sum = digit + scramble;  // 32-bit wraparound, as the reference
-    uint32_t const permuted = digit_of<BASE>(sum, sum / BASE);
-    result = __builtin_fmaf(float(permuted), invBasePow, result);
-    revHash = revHash * BASE + digit;
-    invBasePow *= invBase;
+  if (index > 0) {  // digit 0: empty prefix, the scramble is a constant
+    uint32_t next = index / BASE;
+    uint32_t const d0 = digit_of<BASE>(index, next);
+    result = float(add_mod<BASE>(d0, mix_bits32_c(seed) % BASE)) * invBase;  // fmaf(p, invBase, 0) == p * invBase
     index = next;
+    if (index > 0) {  // digit 1: prefix d0
+      next = index / BASE;
+      uint32_t const d1 = digit_of<BASE>(index, next);
+      result = __builtin_fmaf(float(add_mod<BASE>(d1, c_owen.t[owen_table1_offset(DIM) + d0])), invBase * invBase, result);
+      index = next;
+      uint32_t revHash = d0 * BASE + d1;
+      if (index > 0) {  // digit 2: prefix d0 * BASE + d1
+        next = index / BASE;
+        uint32_t const d2 = digit_of<BASE>(index, next);
+        result = __builtin_fmaf(float(add_mod<BASE>(d2, c_owen.t[owen_table2_offset(DIM) + revHash])), invBase * invBase * invBase, result);
+        index = next;
+        revHash = revHash * BASE + d2;
+        float invBasePow = invBase * invBase * invBase * invBase;
+        while (index > 0) {  // the rest as the reference writes it
+          next = index / BASE;
+          uint32_t const digit = digit_of<BASE>(index, next);
+          uint32_t const scramble = mix_bits32(seed ^ revHash);
+          uint32_t const sum = digit + scramble;  // 32-bit wraparound, as the reference
+          uint32_t const permuted = digit_of<BASE>(sum, sum / BASE);
+          result = __builtin_fmaf(float(permuted), invBasePow, result);
+          revHash = revHash * BASE + digit;
+          invBasePow *= invBase;
+          index = next;
+        }
+      }
+    }
   }
   return fminf(result, 0.99999994f);
 }
@@ -275,11 +355,6 @@ DMT_DEV float radical_inverse(uint32_t index) {  // rng.cu:70-94
     index = next;
   }
   return fminf(result, 0.99999994f);
-}
-template <int DIM, uint32_t BASE>
-DMT_DEV float sample_dim(uint32_t haltonIndex) {  // rng.cu:175-178
-  uint32_t const seed = mix_bits32(1u + (uint32_t(DIM) << 4));
-  return owen_radical_inverse<BASE>(haltonIndex, seed);
 }
 
 // Halton index of sample 0 of a pixel (rng.cu:216-228); add s * stride for sample s
@@ -689,7 +764,6 @@ DMT_DEV LightSample sample_spot_light(Rec32 const& L, f3 position, f2 u, bool ha
   s.distance = fltMax;
   float const radius = h2f(lo16(L.w[7]));
   float const cosThetaE = h2f(hi16(L.w[6]));
-  f3 const spotDir = normalize(dir_from_octa(L.w[5]));
   f3 const lpos = light_pos(L);
   float const radiusSqr = radius * radius;
   f3 lightN = position - lpos;
@@ -705,6 +779,7 @@ DMT_DEV LightSample sample_spot_light(Rec32 const& L, f3 position, f2 u, bool ha
     if (omcHalf < omcSpread) {
       s.direction = sample_uniform_cone(-lightN, omcHalf, u, cosTheta, s.pdf, s.delta);
     } else {
+      f3 const spotDir = normalize(dir_from_octa(L.w[5]));  // decoded only where the spread cone is the narrower one
       s.direction = sample_uniform_cone(-spotDir, omcSpread, u, cosTheta, s.pdf, s.delta);
       if (!ray_sphere(position, s.direction, 0.f, fltMax, lpos, radius, s.pLight, s.distance)) {
         outside = true;
