@@ -118,7 +118,6 @@ struct Traversal {
   int phase;
   bool doC, doS;     // what this round of the lane consists of
   uint32_t cur;
-  uint32_t pend;     // postponed leaf (megakernel_body_bvh): found, not yet tested; kBvhEmpty = none
   BvhStack stack;
   f3 o, d;           // ray of the current phase
   SlabRay2 sr;
@@ -132,7 +131,6 @@ DMT_DEV void trav_set_ray(Traversal& tv, f3 o, f3 d) {
   tv.o = o, tv.d = d;
   tv.sr = slab_ray2(o, d);
   tv.cur = 0u;
-  tv.pend = kBvhEmpty;
   tv.stack.sp = 0;
 }
 template <int K>
@@ -242,25 +240,6 @@ DMT_DEV void trav_leaf(BvhView const& bv, Traversal& tv, TraversalCounters* tc =
   trav_leaf_ref<STATS>(bv, tv, tv.cur, tc);
   tv.cur = (tv.phase != TR_CLOSEST && tv.occluded) ? kBvhEmpty : tv.stack.pop();
 }
-// Postponed leaves (megakernel_body_bvh; "speculative traversal", Aila & Laine 2009): a lane that reaches a leaf parks
-// it in `pend` and goes on with the next stack entry, so it keeps taking part in the wave's NODE steps; the wave runs a
-// LEAF step when enough lanes are blocked (a second leaf found, or nothing else left).  The order in which a ray's
-// nodes and leaves are processed changes, the set of candidates and the comparison rule do not: the closest hit and the
-// any-hit answer are the same (a node visited before its pending leaf was tested is merely culled less tightly).
-DMT_DEV void trav_park_leaf(Traversal& tv) {  // call when cur may be a leaf: park it if the slot is free
-  if (tv.cur != kBvhEmpty && (tv.cur & kBvhLeafFlag) != 0u && tv.pend == kBvhEmpty) {
-    tv.pend = tv.cur;
-    tv.cur = tv.stack.pop();
-  }
-}
-template <bool STATS = false>
-DMT_DEV void trav_leaf_pending(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
-  trav_leaf_ref<STATS>(bv, tv, tv.pend, tc);
-  tv.pend = kBvhEmpty;
-  if (tv.phase != TR_CLOSEST && tv.occluded) tv.cur = kBvhEmpty, tv.stack.sp = 0;  // any-hit: done
-  trav_park_leaf(tv);
-}
-
 // ---- whole traversals of one ray per lane (test kernels, lane_step<BVH>): the same step functions in a loop ----
 template <bool STATS>
 DMT_DEV void trav_run(BvhView const& bv, Traversal& tv, TraversalCounters* tc) {

@@ -1107,8 +1107,8 @@ DMT_DEV void megakernel_body_bvh() {
         int const nNode = __popcll(__ballot(onNode)), nLeaf = __popcll(__ballot(onLeaf));
         if (nNode + nLeaf == 0) break;
         if (__popcll(__ballot(tv.phase == TR_DONE)) >= DMT_BVH_SHADE_THRESHOLD) break;
-        // (parking a found leaf and carrying on with node steps -- bvh_device.hpp trav_park_leaf -- was measured here:
-        //  8 % fewer wave iterations but 5 % slower, the extra dependent LDS pop lengthens every node step)
+        // (parking a found leaf and carrying on with node steps, Aila & Laine's speculative traversal, was measured here in
+        //  round 2 and removed: 8 % fewer wave iterations but 5 % slower, the extra dependent LDS pop lengthens every node step)
 #ifdef DMT_BVH_BOTH_STEPS  // experiment: every traversing lane advances every iteration (node and leaf code both run)
         if constexpr (STATS) ++ls.itNode, ++ls.itLeaf, ls.lanesLeaf += onLeaf ? 1u : 0u;
         if (onNode) trav_node<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
