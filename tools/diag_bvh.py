@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+"""Diagnostic (GPU box): build + validate the BVH of a random soup of n triangles and compare closest hits with brute force."""
 import sys
 from pathlib import Path
 import numpy as np

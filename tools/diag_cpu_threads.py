@@ -1,3 +1,4 @@
+"""Diagnostic (GPU box host): oracle throughput vs thread count (sizing of bench.py's cpu_baseline leg)."""
 import sys, time
 sys.path.insert(0,'/root/repo')
 import __graft_entry__ as g
