@@ -243,11 +243,13 @@ template <uint32_t BASE>
 DMT_DEV uint32_t digit_of(uint32_t x, uint32_t q) {
   return ((q & 0xFFFFFFu) * (0x1000000u - BASE) + x) & 0xFFu;
 }
-// Permutation tables for the first three digits of every dimension.  The Owen scramble of a digit hashes the digits
-// BELOW it, so for digit positions 0, 1, 2 the hash input takes 1, BASE, BASE^2 values: the table holds
-// mix_bits32(seed ^ prefix) % BASE for each of them (124 + 2 384 bytes for the eight dimensions), and the permuted digit
-// (digit + scramble) % BASE becomes an add and a conditional subtract instead of the two-multiply hash and a division.
-// Exact only while digit + scramble does not wrap at 2^32, which `exact` checks for every entry at compile time.
+// Permutation tables for the low digits of every dimension.  The Owen scramble of a digit hashes the digits BELOW it, so
+// at digit position k the hash input takes BASE^k values: for the positions where that is small the table holds
+// mix_bits32(seed ^ prefix) % BASE for each of them, and the permuted digit (digit + scramble) % BASE becomes an add and
+// a conditional subtract instead of the two-multiply hash and a division.  Position 0 needs no table (its scramble is
+// a constant of the dimension); positions 1 .. kOwenTablePositions[d] - 1 are tabulated: 12.4 KB for the eight
+// dimensions, 28 of the ~60 digits of a sample.  Exact only while digit + scramble does not wrap at 2^32, which `exact`
+// checks for every entry at compile time.
 constexpr uint32_t mix_bits32_c(uint32_t v) {
   v ^= v >> 16;
   v *= 0x7feb352dU;
@@ -257,18 +259,25 @@ constexpr uint32_t mix_bits32_c(uint32_t v) {
   return v;
 }
 constexpr uint32_t kOwenBases[8] = {5, 7, 11, 13, 17, 19, 23, 29};  // dimensions 2..9 (rng.cu:175-178 via sampler_values)
+constexpr int kOwenTablePositions[8] = {6, 5, 4, 4, 3, 3, 3, 3};    // digit positions below this come from the table
 constexpr uint32_t owen_seed(int dim) { return mix_bits32_c(1u + (uint32_t(dim) << 4)); }
-constexpr uint32_t owen_table1_offset(int dim) {
+constexpr uint32_t owen_pow(uint32_t base, int k) {
+  uint32_t p = 1;
+  for (int i = 0; i < k; ++i) p *= base;
+  return p;
+}
+constexpr uint32_t owen_dim_bytes(int dim) {  // BASE + BASE^2 + ... + BASE^(P-1)
+  uint32_t n = 0;
+  for (int k = 1; k < kOwenTablePositions[dim - 2]; ++k) n += owen_pow(kOwenBases[dim - 2], k);
+  return n;
+}
+constexpr uint32_t owen_table_offset(int dim, int pos) {  // first entry of digit position `pos` (>= 1) of dimension `dim`
   uint32_t at = 0;
-  for (int i = 0; i < dim - 2; ++i) at += kOwenBases[i];
+  for (int d = 2; d < dim; ++d) at += owen_dim_bytes(d);
+  for (int k = 1; k < pos; ++k) at += owen_pow(kOwenBases[dim - 2], k);
   return at;
 }
-constexpr uint32_t owen_table2_offset(int dim) {
-  uint32_t at = 124;
-  for (int i = 0; i < dim - 2; ++i) at += kOwenBases[i] * kOwenBases[i];
-  return at;
-}
-constexpr uint32_t kOwenTableBytes = 124 + 2384;
+constexpr uint32_t kOwenTableBytes = owen_table_offset(10, 1);
 struct OwenTables {
   uint8_t t[kOwenTableBytes];
   bool exact;
@@ -276,23 +285,23 @@ struct OwenTables {
 constexpr OwenTables make_owen_tables() {
   OwenTables T{};
   T.exact = true;
+  uint32_t at = 0;
   for (int dim = 2; dim < 10; ++dim) {
     uint32_t const base = kOwenBases[dim - 2], seed = owen_seed(dim);
     if (mix_bits32_c(seed) > 0xFFFFFFFFu - (base - 1u)) T.exact = false;  // position 0 (a constant, see sample_dim)
-    for (uint32_t prefix = 0; prefix < base; ++prefix) {
-      uint32_t const sc = mix_bits32_c(seed ^ prefix);
-      if (sc > 0xFFFFFFFFu - (base - 1u)) T.exact = false;
-      T.t[owen_table1_offset(dim) + prefix] = uint8_t(sc % base);
-    }
-    for (uint32_t prefix = 0; prefix < base * base; ++prefix) {
-      uint32_t const sc = mix_bits32_c(seed ^ prefix);
-      if (sc > 0xFFFFFFFFu - (base - 1u)) T.exact = false;
-      T.t[owen_table2_offset(dim) + prefix] = uint8_t(sc % base);
+    for (int pos = 1; pos < kOwenTablePositions[dim - 2]; ++pos) {
+      uint32_t const n = owen_pow(base, pos);
+      for (uint32_t prefix = 0; prefix < n; ++prefix) {
+        uint32_t const sc = mix_bits32_c(seed ^ prefix);
+        if (sc > 0xFFFFFFFFu - (base - 1u)) T.exact = false;
+        T.t[at++] = uint8_t(sc % base);
+      }
     }
   }
+  if (at != kOwenTableBytes) T.exact = false;
   return T;
 }
-static_assert(owen_table2_offset(10) == kOwenTableBytes, "table size");
+static_assert(kOwenTableBytes == 12655, "table size");
 static_assert(make_owen_tables().exact, "a scramble within BASE of 2^32: that prefix needs the wrapping sum");
 __constant__ OwenTables c_owen = make_owen_tables();
 
@@ -302,42 +311,45 @@ DMT_DEV uint32_t add_mod(uint32_t digit, uint32_t scrambleModBase) {  // (digit 
   uint32_t const w = t - BASE;  // wraps to a huge value when t < BASE
   return t < w ? t : w;
 }
+constexpr float owen_inv_pow(uint32_t base, int k) {  // invBase multiplied up k times in float, as the reference's loop does
+  float const invBase = 1.0f / float(base);
+  float p = invBase;
+  for (int i = 1; i < k; ++i) p *= invBase;
+  return p;
+}
 template <int DIM, uint32_t BASE>
 DMT_DEV float sample_dim(uint32_t index) {  // owenScrambledRadicalInverse, rng.cu:137-178
   static_assert(kOwenBases[DIM - 2] == BASE, "dimension / base");
   constexpr uint32_t seed = owen_seed(DIM);
+  constexpr int P = kOwenTablePositions[DIM - 2];
   float const invBase = 1.0f / float(BASE);  // correctly rounded at compile time (= __frcp_rn)
   float result = 0.0f;
   if (index > 0) {  // digit 0: empty prefix, the scramble is a constant
     uint32_t next = index / BASE;
-    uint32_t const d0 = digit_of<BASE>(index, next);
-    result = float(add_mod<BASE>(d0, mix_bits32_c(seed) % BASE)) * invBase;  // fmaf(p, invBase, 0) == p * invBase
+    uint32_t revHash = digit_of<BASE>(index, next);
+    result = float(add_mod<BASE>(revHash, mix_bits32_c(seed) % BASE)) * invBase;  // fmaf(p, invBase, 0) == p * invBase
     index = next;
-    if (index > 0) {  // digit 1: prefix d0
+#pragma unroll
+    for (int pos = 1; pos < P; ++pos) {  // tabulated positions: prefix = the digits so far
+      if (index == 0) break;
       next = index / BASE;
-      uint32_t const d1 = digit_of<BASE>(index, next);
-      result = __builtin_fmaf(float(add_mod<BASE>(d1, c_owen.t[owen_table1_offset(DIM) + d0])), invBase * invBase, result);
+      uint32_t const digit = digit_of<BASE>(index, next);
+      uint32_t const permuted = add_mod<BASE>(digit, c_owen.t[owen_table_offset(DIM, pos) + revHash]);
+      result = __builtin_fmaf(float(permuted), owen_inv_pow(BASE, pos + 1), result);
+      revHash = revHash * BASE + digit;
       index = next;
-      uint32_t revHash = d0 * BASE + d1;
-      if (index > 0) {  // digit 2: prefix d0 * BASE + d1
-        next = index / BASE;
-        uint32_t const d2 = digit_of<BASE>(index, next);
-        result = __builtin_fmaf(float(add_mod<BASE>(d2, c_owen.t[owen_table2_offset(DIM) + revHash])), invBase * invBase * invBase, result);
-        index = next;
-        revHash = revHash * BASE + d2;
-        float invBasePow = invBase * invBase * invBase * invBase;
-        while (index > 0) {  // the rest as the reference writes it
-          next = index / BASE;
-          uint32_t const digit = digit_of<BASE>(index, next);
-          uint32_t const scramble = mix_bits32(seed ^ revHash);
-          uint32_t const sum = digit + scramble;  // 32-bit wraparound, as the reference
-          uint32_t const permuted = digit_of<BASE>(sum, sum / BASE);
-          result = __builtin_fmaf(float(permuted), invBasePow, result);
-          revHash = revHash * BASE + digit;
-          invBasePow *= invBase;
-          index = next;
-        }
-      }
+    }
+    float invBasePow = owen_inv_pow(BASE, P + 1);
+    while (index > 0) {  // the rest as the reference writes it
+      next = index / BASE;
+      uint32_t const digit = digit_of<BASE>(index, next);
+      uint32_t const scramble = mix_bits32(seed ^ revHash);
+      uint32_t const sum = digit + scramble;  // 32-bit wraparound, as the reference
+      uint32_t const permuted = digit_of<BASE>(sum, sum / BASE);
+      result = __builtin_fmaf(float(permuted), invBasePow, result);
+      revHash = revHash * BASE + digit;
+      invBasePow *= invBase;
+      index = next;
     }
   }
   return fminf(result, 0.99999994f);
