@@ -267,17 +267,19 @@ def main():
     mean, m2 = film[0], film[1]
     r.film_bind(mean.data_ptr(), m2.data_ptr())
 
-    def step():
+    # N > 1: stream events around every combine, so that a scaling curve can be decomposed per rank into
+    # kernel time (the library's own HIP events), combine time and the wait for the slowest rank
+    comb_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if world > 1 else []
+
+    def step(timed_index=None):
         film.zero_()
         for s0 in range(0, spp, kspp):
             r.render(min(kspp, spp - s0), sample_offset=s0)
-        if world > 1 and backend != "nccl":
-            # gloo rehearsal (ranks SHARE one GPU): gloo stages the device tensor through the host in many small stream
-            # operations; issued while the other ranks' persistent kernels hold the GPU, each of them waits for a time
-            # slice of the shared device (4 ranks: 71 s per step instead of 0.35 s).  Draining the stream first lets them
-            # run back to back.  Not needed, and not done, on the RCCL path (one GPU per rank, stream-ordered collective).
-            torch.cuda.synchronize(dev)
+        if timed_index is not None and comb_ev:
+            comb_ev[timed_index][0].record(stream)
         pkg.multigpu.combine_films(mean, m2, dst=0, film=film)  # disjoint tiles + zero frames: SUM-reduce == exact gather
+        if timed_index is not None and comb_ev:
+            comb_ev[timed_index][1].record(stream)
 
     def barrier():
         if world > 1:
@@ -288,18 +290,38 @@ def main():
         step()
     barrier()
     r.kernel_time(reset=True)
+    r.sched_diag(reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     torch.cuda.synchronize(dev)
+    t_local = time.perf_counter() - t0      # this rank's own K steps (render + combine), before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    t_barrier = elapsed - t_local
     kernel_ms, launches = r.kernel_time(reset=True)
-    r.sync()   # every rank: raises DmtError if a fold gave up waiting (in-launch ordering) -> non-zero exit, no JSON line
+    sched = r.sched_diag()   # syncs; hand-over counters of the timed launches
+    r.sync()   # every rank: raises DmtError if a launch did not fold every sample chunk exactly once -> non-zero exit, no JSON line
+    per_rank = None
+    if world > 1:
+        combine_ms = sum(a.elapsed_time(b) for a, b in comb_ev)
+        mine = torch.tensor([elapsed, kernel_ms / args.steps, combine_ms / args.steps, t_local / args.steps * 1e3, t_barrier * 1e3,
+                             sched["handed_over"], sched["folded_for_others"], sched["slab_stalls"], sched["early_exits"],
+                             sched["max_stall_ticks_10ns"]], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = torch.stack(allr).cpu().numpy()
+        elapsed = float(rows[:, 0].max())   # MAX over ranks
+        per_rank = {"kernel_ms_per_step": [round(float(x), 3) for x in rows[:, 1]],
+                    "combine_ms_per_step": [round(float(x), 3) for x in rows[:, 2]],
+                    "local_ms_per_step": [round(float(x), 3) for x in rows[:, 3]],
+                    "final_barrier_wait_ms": [round(float(x), 3) for x in rows[:, 4]],
+                    "note": "kernel = the library's HIP events around each megakernel launch; combine = stream events around the "
+                            "reduce (on rank 0 it includes waiting for the slowest sender); local = this rank's K steps on its own "
+                            "clock; final barrier wait = time spent in the closing barrier"}
+        sched = {"handed_over": int(rows[:, 5].sum()), "folded_for_others": int(rows[:, 6].sum()), "slab_stalls": int(rows[:, 7].sum()),
+                 "early_exits": int(rows[:, 8].sum()), "max_stall_ticks_10ns": int(rows[:, 9].max()),
+                 "folds": None, "launched": None, "slabs_per_wave": sched["slabs_per_wave"]}
 
     total_samples = float(width) * height * spp * args.steps
     value = total_samples / elapsed / 1e6
@@ -412,6 +434,8 @@ def main():
                        "combine": "rccl reduce(sum) of mean/M2 frames to rank 0" if world > 1 else "none"},
             "film_ok": counts_ok,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+            "per_rank": per_rank,
+            "fold_handover": sched,   # in-launch ordered fold without waiting: chunks handed to another wave, stalls, early exits
         }
         print(json.dumps(out), flush=True)
         if not counts_ok or (parity is not None and not parity["rmse_vs_cpu_rows"] < parity["tolerance"]):

@@ -54,7 +54,7 @@ EXPORTED_SYMBOLS = [
     "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_light_sampling", "dmt_light_tree_pmfs", "dmt_set_bvh_strategy", "dmt_set_partition", "dmt_set_chunk", "dmt_render_profile",
     "dmt_upload_area_lights", "dmt_upload_textures", "dmt_upload_envmap", "dmt_clear_envmap", "dmt_envmap_tables", "dmt_test_envmap",
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
-    "dmt_render", "dmt_render_stats", "dmt_sync", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
+    "dmt_render", "dmt_render_stats", "dmt_sync", "dmt_sched_diag", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
     "dmt_test_sampler", "dmt_test_camera_rays", "dmt_test_bsdf", "dmt_test_light", "dmt_test_half",
     "dmt_test_trace_samples", "dmt_test_trace_log", "dmt_test_closest_hit",
 ]
@@ -296,6 +296,16 @@ class Renderer:
 
     def sync(self):
         self._check(self._lib.dmt_sync(self._ctx), "dmt_sync")
+
+    def sched_diag(self, reset=False):
+        """Counters of the in-launch fold hand-over (dmt_sched_diag); synchronises the stream."""
+        out = (C.c_uint64 * 8)()
+        if not hasattr(self._lib, "dmt_sched_diag"):   # an older build loaded through DMT_HIP_LIB for an A/B run
+            return dict.fromkeys(["folds", "handed_over", "folded_for_others", "slab_stalls", "early_exits",
+                                  "max_stall_ticks_10ns", "launched", "slabs_per_wave"], 0)
+        self._check(self._lib.dmt_sched_diag(self._ctx, out, int(bool(reset))), "dmt_sched_diag")
+        keys = ["folds", "handed_over", "folded_for_others", "slab_stalls", "early_exits", "max_stall_ticks_10ns", "launched", "slabs_per_wave"]
+        return dict(zip(keys, [int(x) for x in out]))
 
     def kernel_time(self, reset=True):
         ms, n = C.c_double(), C.c_uint64()

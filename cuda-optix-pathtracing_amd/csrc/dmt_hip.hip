@@ -53,9 +53,10 @@ struct RenderParams {
   uint32_t sampleOffset, spp;
   uint32_t chunkSpp;       // samples per work item
   uint32_t numChunks;      // ceil(spp / chunkSpp)
-  float* stage;            // per-wave staging of finished samples: [wave][slot 0/1][chunkSpp][64] float3
-  uint32_t* tileDone;      // [numItems] chunks completed per owned tile (in-launch ordering of a tile's chunks)
-  uint32_t* errorFlag;     // set if a bounded wait gives up
+  float* stage;            // staging slabs of finished samples: [wave][kSlabsPerWave][chunkSpp][64] float3
+  uint32_t* link;          // [numChunks][numItems] hand-over word of (chunk, tile): 0, kFoldReady or slab + 1 (item_complete)
+  uint32_t* slabBusy;      // [wave][kSlabsPerWave] 1 while a handed-over slab waits for its folder
+  unsigned long long* schedDiag;  // kSchedDiagWords counters, accumulated over launches (dmt_sched_diag)
   int maxDepth;
   EnvView env;                // A18 env map (w == 0: none); read by the *_env kernels only
   // SURVEY 8f-3 emissive triangles; read by the *_area kernels only
@@ -685,7 +686,11 @@ DMT_DEV void path_begin_prepared(PathState& st) {
 #ifndef DMT_MIN_WAVES_PER_SIMD_BVH
 #define DMT_MIN_WAVES_PER_SIMD_BVH 3
 #endif
-constexpr uint32_t kMaxChunkSpp = 512;  // staging: 384 KB per wave at most
+constexpr uint32_t kMaxChunkSpp = 512;  // staging: 384 KB per slab at most
+#ifndef DMT_SLABS_PER_WAVE
+#define DMT_SLABS_PER_WAVE 4
+#endif
+constexpr int kSlabsPerWave = DMT_SLABS_PER_WAVE;  // staging slabs per wave: two live items + two handed over
 #ifndef DMT_PREP_THRESHOLD
 #define DMT_PREP_THRESHOLD 64
 #endif
@@ -695,8 +700,8 @@ struct TileArgs {  // what a wave needs when it picks up a new work item
   uint32_t* counter;
   int width, x0, y0, x1, y1, tx0, ty0, rtx;
   uint32_t numItems, subShift, sampleOffset, spp, chunkSpp, numChunks;
-  uint32_t* tileDone;
-  uint32_t* errorFlag;
+  uint32_t* link;
+  uint32_t* slabBusy;
   float* stage;
   int rank, world;
 };
@@ -706,7 +711,7 @@ DMT_DEV TileArgs load_tile_args(KArgs k) {
   t.mean = k->mean, t.m2 = k->m2, t.counter = k->counter, t.width = k->width;
   t.x0 = k->x0, t.y0 = k->y0, t.x1 = k->x1, t.y1 = k->y1, t.tx0 = k->tx0, t.ty0 = k->ty0, t.rtx = k->rtx;
   t.numItems = k->numItems, t.subShift = k->subShift, t.sampleOffset = k->sampleOffset, t.spp = k->spp, t.rank = k->rank, t.world = k->world;
-  t.chunkSpp = k->chunkSpp, t.numChunks = k->numChunks, t.tileDone = k->tileDone, t.errorFlag = k->errorFlag, t.stage = k->stage;
+  t.chunkSpp = k->chunkSpp, t.numChunks = k->numChunks, t.link = k->link, t.slabBusy = k->slabBusy, t.stage = k->stage;
   return t;
 }
 
@@ -719,29 +724,42 @@ DMT_DEV TileArgs load_tile_args(KArgs k) {
 //   requests is one sample of every pixel).  Path lengths differ between pixels (glass vs wall) and between
 //   samples; with lane == pixel every item ran at the pace of its slowest pixel, now the wave stays full
 //   until the item runs out of units.
-// * A finished sample's radiance goes to the wave's staging area in global memory ([sample][pixel] float3,
-//   12 B written + 12 B read per sample against ~10^4 instructions to trace one).  When all units of an item
-//   are staged the wave FOLDS it: waits until chunk c-1 of the same tile is in the film (per-tile completion
-//   counter), reads the pixels' running (mean, M2, N), applies the reference's Welford update
-//   (SMEMLayout::updateSample, T/megakernel/megakernel.cuh:59-79) to the staged samples in index order,
-//   writes the film and publishes c.  The film is therefore bit-identical for every chunk size and schedule,
-//   and chunks c and c+1 of one tile are traced CONCURRENTLY by different waves: a small frame, or one GPU's
-//   share of a frame split eight ways (2 048 tiles for 4 096 resident waves), still fills the machine.
-// * A wave holds up to TWO live items (sequence numbers cur and cur+1, slots seq & 1): when item cur has no
-//   units left, free lanes draw from item cur+1 (fetched at that moment) while the last paths of cur drain;
-//   when cur's last sample is staged the wave folds it (lane i folds pixel i; whatever lane i is tracing
+// * A finished sample's radiance goes to one of the wave's kSlabsPerWave staging SLABS in global memory
+//   ([sample][pixel] float3, written through so that any wave can read it back).  The film is the reference's
+//   Welford update (SMEMLayout::updateSample, T/megakernel/megakernel.cuh:59-79) applied to a pixel's samples
+//   IN INDEX ORDER, so chunk c of a tile must be folded after chunk c-1 -- while chunks c and c+1 are traced
+//   CONCURRENTLY by different waves (a small frame, or one GPU's share of a frame split eight ways, still fills
+//   the machine).  Nobody waits for that order; the fold is HANDED OVER instead (item_complete):
+//     - every (chunk, tile) has one hand-over word `link`, zero at launch.  Exactly two parties touch it, each
+//       with ONE atomic exchange: the wave that finishes tracing chunk c writes "slab + 1", the wave that has
+//       put chunk c-1 into the film writes kFoldReady.  Exchanges on one word are totally ordered, so exactly
+//       one of the two sees the other's value, and that one folds chunk c: the finisher if the predecessor was
+//       already in the film, else the predecessor's folder, which then goes on to chunk c+1 the same way
+//       (fold_chain).  Chunk 0 is folded by its finisher.
+//     - a slab that was handed over stays busy until its folder clears `slabBusy`; its owner meanwhile uses
+//       another of its slabs.
+//   The film is therefore bit-identical for every chunk size and schedule, and no wave ever spins on another
+//   wave's progress while it holds work: the only wait left is a wave with NO live item whose slabs are all
+//   handed over and not folded yet (sched_retire) -- it holds nothing anybody needs, polls for a bounded wall
+//   clock time and then EXITS (the remaining items are fetched by the other waves; counted in schedDiag).
+//   Round 2's protocol had the finisher spin on a per-tile completion counter instead.  That is deadlock-free
+//   only if every wave that has fetched an item keeps running; it gave up (error flag, 71 s per step) when four
+//   processes' persistent kernels shared one GPU (DESIGN.md 7 has the record).
+// * A wave holds up to TWO live items (sequence numbers cur and cur+1, LDS slots seq & 1): when item cur has
+//   no units left, free lanes draw from item cur+1 (fetched at that moment) while the last paths of cur drain;
+//   when cur's last sample is staged the wave completes it (lane i folds pixel i; whatever lane i is tracing
 //   meanwhile stays in its registers).  Small items are therefore cheap, which keeps the end-of-launch tail
 //   short when a frame is split over 8 GPUs.
-//
-// Deadlock freedom: a fold of item w waits only for the item of the same tile one chunk earlier, which has
-// a smaller work index; a wave folds its items in increasing index order; every index below a fetched one
-// has been fetched by a resident wave (persistent launch).  So waits always point to strictly smaller
-// indices and the smallest live item waits for nothing.  The wait is bounded anyway.
-__shared__ uint32_t s_desc[kLdsThreads / 64][2][8];  // per wave, per slot: chunk, tile item, px0, py0, s0, n, nInside
+__shared__ uint32_t s_desc[kLdsThreads / 64][2][8];  // per wave, per slot: chunk, tile item, px0, py0, s0, first float of the slab, nInside, slab
 __shared__ int32_t s_pixbase[2 * kLdsThreads];       // per slot, per pixel: Halton pixel base, -1 = outside the region
 __shared__ uint32_t s_pixmap[2 * kLdsThreads];       // per slot: j-th pixel inside the region
 
 constexpr uint32_t kSlotBit = 0x80000000u;  // staging index = slot bit | (sample * 64 + pixel)
+constexpr uint32_t kFoldReady = 0xFFFFFFFFu;  // link word: the tile's previous chunk is in the film
+#ifndef DMT_SLAB_WAIT_MS
+#define DMT_SLAB_WAIT_MS 250  // a wave without a live item and without a free slab polls this long, then exits
+#endif
+constexpr int kSchedDiagWords = 8;  // folds, handed over, folded for another wave, stalls, early exits, max stall ticks
 
 // wave-level bookkeeping (all wave-uniform)
 struct WaveSched {
@@ -749,52 +767,109 @@ struct WaveSched {
   uint32_t alloc = 0;                     // item units are drawn from
   uint32_t nextUnit = 0, totalUnits = 0;  // cursor / size of item `alloc`
   bool exhausted = false;                 // the launch has no more items
+  uint32_t slabFree = (1u << kSlabsPerWave) - 1u;  // own slabs that are free
+  uint32_t slabPend = 0;                           // own slabs handed over, not known to be folded yet
 };
+// launch diagnostics (dmt_sched_diag; the host checks folds == items): one atomic per EVENT, from lane 0 -- an event is at
+// most once per work item (~10^3 path samples), and counters kept in the wave's registers cost spills in the hot loop
+enum { SD_FOLDS = 0, SD_HANDED = 1, SD_CHAINED = 2, SD_STALLS = 3, SD_EXITS = 4, SD_MAXSTALL = 5 };
+DMT_DEV void sched_count(unsigned long long* D, int lane, int what, unsigned long long n = 1ull) {
+  if (lane == 0) atomicAdd(&D[what], n);
+}
 // per-lane bookkeeping
 struct LaneSched {
   bool prepared = false;  // a unit is waiting in s_prep
   bool prepSlot = false;  // ... of the item in this slot
 };
 
-// fetch the next work item into slot seq & 1; false = the launch has no more items
-DMT_DEV bool item_fetch(KArgs Pk, int lane, uint32_t seq, uint32_t& units) {
+// pixel origin and row count of a tile item (an owned tile is scheduled as 1 << subShift bands of 8 >> subShift
+// rows: more, smaller items when this GPU has fewer tiles than resident waves; lanes beyond the band are "outside")
+struct ItemGeom {
+  int px0, py0;
+  uint32_t rows;
+};
+DMT_DEV ItemGeom item_geom(TileArgs const& T, uint32_t item) {
+  uint32_t const band = item & ((1u << T.subShift) - 1u);
+  uint32_t const rows = 8u >> T.subShift;
+  uint32_t const j = uint32_t(T.rank) + (item >> T.subShift) * uint32_t(T.world);
+  return {(T.tx0 + int(j % uint32_t(T.rtx))) * 8, (T.ty0 + int(j / uint32_t(T.rtx))) * 8 + int(band * rows), rows};
+}
+DMT_DEV bool item_lane_inside(TileArgs const& T, ItemGeom const& g, int lane) {
+  int const px = g.px0 + (lane & 7), py = g.py0 + (lane >> 3);
+  return uint32_t(lane >> 3) < g.rows && px >= T.x0 && px < T.x1 && py >= T.y0 && py < T.y1;
+}
+DMT_DEV uint32_t chunk_samples(TileArgs const& T, uint32_t chunk) {
+  uint32_t const s0 = chunk * T.chunkSpp;
+  return s0 + T.chunkSpp < T.spp ? T.chunkSpp : T.spp - s0;
+}
+
+// index of this wave in the launch, as a value the compiler knows to be wave-uniform (gtid >> 6 lives in a VGPR; slab
+// bookkeeping derived from it would be treated as divergent: VALU bit scans, exec-masked branches around item_fetch)
+DMT_DEV uint32_t wave_index(uint32_t gtid) { return uint32_t(__builtin_amdgcn_readfirstlane(int(gtid >> 6))); }
+
+// which of the wave's handed-over slabs have been folded meanwhile?
+DMT_DEV void slab_refresh(TileArgs const& T, uint32_t gtid, int lane, WaveSched& W) {
+  if (W.slabPend == 0u) return;
+  bool const mine = lane < kSlabsPerWave && ((W.slabPend >> lane) & 1u) != 0u;
+  uint32_t busy = 1u;
+  if (mine) busy = __hip_atomic_load(&T.slabBusy[wave_index(gtid) * kSlabsPerWave + uint32_t(lane)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t const freed = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(__ballot(mine && busy == 0u)))));
+  W.slabFree |= freed, W.slabPend &= ~freed;
+}
+
+// fetch the next work item into slot seq & 1; false = the launch has no more items.  The caller has checked that the
+// wave has a free slab (W.slabFree != 0; slab_refresh runs in sched_retire only, to keep it out of the hot loop).
+DMT_DEV bool item_fetch(KArgs Pk, uint32_t gtid, int lane, uint32_t seq, WaveSched& W, uint32_t& units) {
   TileArgs const T = load_tile_args(Pk);
   uint32_t work = 0;
   if (lane == 0) work = atomicAdd(T.counter, 1u);
   work = uint32_t(__builtin_amdgcn_readfirstlane(int(work)));
   if (work >= T.numItems * T.numChunks) return false;
+  uint32_t const slabK = uint32_t(__builtin_ctz(W.slabFree));
+  W.slabFree &= ~(1u << slabK);
   uint32_t const chunk = work / T.numItems;
   uint32_t const item = work - chunk * T.numItems;
-  // an owned tile is scheduled as 1 << subShift bands of 8 >> subShift rows: more, smaller items when this GPU
-  // has fewer tiles than resident waves (lanes beyond the band are simply "outside")
-  uint32_t const band = item & ((1u << T.subShift) - 1u);
-  uint32_t const rows = 8u >> T.subShift;
-  uint32_t const j = uint32_t(T.rank) + (item >> T.subShift) * uint32_t(T.world);
-  int const px0 = (T.tx0 + int(j % uint32_t(T.rtx))) * 8;
-  int const py0 = (T.ty0 + int(j / uint32_t(T.rtx))) * 8 + int(band * rows);
-  int const px = px0 + (lane & 7), py = py0 + (lane >> 3);
-  bool const inside = uint32_t(lane >> 3) < rows && px >= T.x0 && px < T.x1 && py >= T.y0 && py < T.y1;
+  ItemGeom const g = item_geom(T, item);
+  int const px = g.px0 + (lane & 7), py = g.py0 + (lane >> 3);
+  bool const inside = item_lane_inside(T, g, lane);
   uint32_t const s0 = T.sampleOffset + chunk * T.chunkSpp;
-  uint32_t const s1 = s0 + T.chunkSpp < T.sampleOffset + T.spp ? s0 + T.chunkSpp : T.sampleOffset + T.spp;
+  uint32_t const n = chunk_samples(T, chunk);
   uint32_t const slot = seq & 1u;
   unsigned long long const insideMask = __ballot(inside);
   uint32_t const nInside = uint32_t(__popcll(insideMask));
   uint32_t* const d = s_desc[threadIdx.x >> 6][slot];  // wave-uniform values: every lane stores the same words
-  d[0] = chunk, d[1] = item, d[2] = uint32_t(px0), d[3] = uint32_t(py0), d[4] = s0, d[5] = s1 - s0, d[6] = nInside;
+  d[0] = chunk, d[1] = item, d[2] = uint32_t(g.px0), d[3] = uint32_t(g.py0), d[4] = s0, d[6] = nInside;
+  d[7] = wave_index(gtid) * kSlabsPerWave + slabK;
+  d[5] = d[7] * T.chunkSpp * 192u;  // first float of the slab (< 2^32: at most 16 384 slabs of kMaxChunkSpp * 192 floats)
   uint32_t const wbase = slot * kLdsThreads + (threadIdx.x & ~63u);
   s_pixbase[wbase + lane] = inside ? halton_pixel_base(load_cold_args(Pk).sp, px, py) : -1;
   if (inside) s_pixmap[wbase + uint32_t(__popcll(insideMask & ((1ull << lane) - 1ull)))] = uint32_t(lane);
-  units = nInside * (s1 - s0);
+  units = nInside * n;
   return true;
 }
 
-DMT_DEV float* stage_slab(KArgs Pk, uint32_t gtid, uint32_t slot) {
-  KArgs const k = kargs(Pk);
-  return k->stage + size_t((gtid >> 6) * 2u + slot) * size_t(k->chunkSpp) * 192u;
-}
-DMT_DEV void stage_sample(KArgs Pk, uint32_t gtid, uint32_t sidx, f3 L) {
-  float* const p = stage_slab(Pk, gtid, sidx >> 31) + size_t(sidx & ~kSlotBit) * 3u;
+// Staged radiance goes to the wave's slab with PLAIN stores (they merge in this XCD's L2; the owner folds its own slab
+// from there).  Only when a slab is handed over is it made visible to the other XCDs (slab_publish).
+DMT_DEV void stage_sample(KArgs Pk, uint32_t sidx, f3 L) {
+  uint32_t const first = s_desc[threadIdx.x >> 6][sidx >> 31][5];
+  float* const p = kargs(Pk)->stage + (first + (sidx & ~kSlotBit) * 3u);
   p[0] = L.x, p[1] = L.y, p[2] = L.z;
+}
+// Hand-over: the folder may run on another XCD, whose L2 is a different one, and this XCD's L2 holds the slab as dirty
+// lines.  Writing back the whole L2 (release fence = buffer_wbl2) would cost far more than the slab is worth, so the
+// owner re-stores its n x 64 x 3 floats with agent-scope stores (global_store ... sc1: written through to memory), lane i
+// the samples of pixel i; the folder reads them with agent-scope loads.  48 loads + 48 stores per lane for 16 samples,
+// paid only by chunks that finish before their predecessor (none on a frame with more tiles than resident waves).
+DMT_DEV void slab_publish(TileArgs const& T, int lane, uint32_t slab, uint32_t n) {
+  float* p = T.stage + size_t(slab) * size_t(T.chunkSpp) * 192u + uint32_t(lane) * 3u;
+#pragma unroll 4
+  for (uint32_t k = 0; k < n; ++k, p += 192) {
+    float const x = p[0], y = p[1], z = p[2];
+    uint32_t* const q = reinterpret_cast<uint32_t*>(p);
+    __hip_atomic_store(q + 0, __float_as_uint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, __float_as_uint(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 2, __float_as_uint(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // prepare unit u of item `seq` in this lane's s_prep
@@ -814,9 +889,8 @@ DMT_DEV void prepare_unit(KArgs Pk, uint32_t seq, uint32_t u, LaneSched& Ls) {
 
 // Film words that another wave of this launch may read or have written (the tile's previous / next chunk) are
 // moved with agent-scope relaxed atomics (global_load/store ... sc1: coherent across the XCDs' L2s) and
-// ordered against the completion counter by s_waitcnt.  The obvious alternative, plain accesses between
-// acquire/release FENCES, costs a buffer_inv / buffer_wbl2 of the XCD's whole L2 per item -- and the L2 is
-// full of dirty staging lines that nobody else will ever read.
+// ordered against the hand-over word by s_waitcnt.  The obvious alternative, plain accesses between
+// acquire/release FENCES, costs a buffer_inv / buffer_wbl2 of the XCD's whole L2 per item.
 DMT_DEV float4 film_load(float4 const* p) {
   unsigned long long const* const q = reinterpret_cast<unsigned long long const*>(p);
   unsigned long long const a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -842,71 +916,110 @@ DMT_DEV void welford_update(f3& mean, f3& M2, float& N, f3 L) {
   M2 = M2 + delta * delta2;
 }
 
-DMT_DEV void item_fold(KArgs Pk, uint32_t gtid, int lane, uint32_t seq) {
-  TileArgs const T = load_tile_args(Pk);
-  uint32_t const slot = seq & 1u;
-  uint32_t const* const d = s_desc[threadIdx.x >> 6][slot];
-  uint32_t const chunk = uint32_t(__builtin_amdgcn_readfirstlane(int(d[0])));
-  uint32_t const item = uint32_t(__builtin_amdgcn_readfirstlane(int(d[1])));
-  uint32_t const n = uint32_t(__builtin_amdgcn_readfirstlane(int(d[5])));
-  int const px = int(d[2]) + (lane & 7), py = int(d[3]) + (lane >> 3);
-  bool const inside = s_pixbase[slot * kLdsThreads + threadIdx.x] >= 0;
-  if (chunk > 0) {
-    if (lane == 0) {
-      uint32_t spins = 0;
-      while (__hip_atomic_load(&T.tileDone[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 26)) {  // ~minutes: something is badly wrong, do not hang the GPU
-          __hip_atomic_store(T.errorFlag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // counter seen; own staging stores have landed
+// Put chunk `chunk` of tile item `item` (staged in `slab`) into the film -- the caller knows that chunk - 1 is there --
+// and then every directly following chunk that has already been handed over.  Lane i folds pixel i of the tile.
+DMT_DEV void fold_chain(TileArgs const& T, unsigned long long* D, uint32_t gtid, int lane, uint32_t item, uint32_t chunk, uint32_t slab) {
+  ItemGeom const g = item_geom(T, item);
+  bool const inside = item_lane_inside(T, g, lane);
+  size_t const pidx = size_t(g.px0 + (lane & 7)) + size_t(g.py0 + (lane >> 3)) * size_t(T.width);
+  f3 mean = mk3(0, 0, 0), M2 = mk3(0, 0, 0);
+  float N = 0.f;
+  uint32_t folded = 0;
   if (inside) {
-    size_t const pidx = size_t(px) + size_t(py) * size_t(T.width);
     float4 const m = film_load(T.mean + pidx);  // SMEMLayout::startSample, megakernel.cuh:45-57
     float4 const v = film_load(T.m2 + pidx);
-    f3 mean = mk3(m.x, m.y, m.z), M2 = mk3(v.x, v.y, v.z);
-    float N = v.w;
-    float const* p = stage_slab(Pk, gtid, slot) + uint32_t(lane) * 3u;
-#pragma unroll 8
-    for (uint32_t k = 0; k < n; ++k, p += 192) welford_update(mean, M2, N, mk3(p[0], p[1], p[2]));
-    film_store(T.mean + pidx, make_float4(mean.x, mean.y, mean.z, 0.f));  // endSample, megakernel.cuh:81-85
-    film_store(T.m2 + pidx, make_float4(M2.x, M2.y, M2.z, N));
+    mean = mk3(m.x, m.y, m.z), M2 = mk3(v.x, v.y, v.z), N = v.w;
   }
-  if (T.numChunks > 1) {  // publish: film stores complete (written through) -> completion counter
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(&T.tileDone[item], chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    uint32_t const n = chunk_samples(T, chunk);
+    bool const own = slab / kSlabsPerWave == wave_index(gtid);  // wave-uniform
+    float const* p = T.stage + size_t(slab) * size_t(T.chunkSpp) * 192u + uint32_t(lane) * 3u;
+    if (inside) {
+      if (own) {
+#pragma unroll 4
+        for (uint32_t k = 0; k < n; ++k, p += 192) welford_update(mean, M2, N, mk3(p[0], p[1], p[2]));
+      } else {  // another wave's slab: read it where it was written through to
+#pragma unroll 2
+        for (uint32_t k = 0; k < n; ++k, p += 192) {
+          uint32_t const* const q = reinterpret_cast<uint32_t const*>(p);
+          uint32_t const x = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          uint32_t const y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          uint32_t const z = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          welford_update(mean, M2, N, mk3(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z)));
+        }
+      }
+      film_store(T.mean + pidx, make_float4(mean.x, mean.y, mean.z, 0.f));  // endSample, megakernel.cuh:81-85
+      film_store(T.m2 + pidx, make_float4(M2.x, M2.y, M2.z, N));
+    }
+    ++folded;
+    if (++chunk == T.numChunks) {  // (a foreign slab of the last chunk still has to be released)
+      if (!own) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&T.slabBusy[slab], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slab read, film stores written through -> release the slab, publish
+    uint32_t next = 0;
+    if (lane == 0) {
+      if (!own) __hip_atomic_store(&T.slabBusy[slab], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      next = __hip_atomic_exchange(&T.link[size_t(chunk) * T.numItems + item], kFoldReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    next = uint32_t(__builtin_amdgcn_readfirstlane(int(next)));
+    if (next == 0u) break;  // chunk not finished yet: its finisher will find kFoldReady and fold it
+    slab = next - 1u;       // finished and handed over: this wave folds it (the running statistics are in registers)
   }
+  sched_count(D, lane, SD_FOLDS, folded);
+  if (folded > 1u) sched_count(D, lane, SD_CHAINED, folded - 1u);
 }
 
-// has the tile's previous chunk been folded, i.e. may item `seq` be folded without waiting?
-DMT_DEV bool fold_ready(KArgs Pk, int lane, uint32_t seq) {
+// Item `seq` of this wave is completely staged: fold it, or hand it over to the folder of the tile's previous chunk.
+DMT_DEV void item_complete(KArgs Pk, uint32_t gtid, int lane, uint32_t seq, WaveSched& W) {
+  TileArgs const T = load_tile_args(Pk);
   uint32_t const* const d = s_desc[threadIdx.x >> 6][seq & 1u];
   uint32_t const chunk = uint32_t(__builtin_amdgcn_readfirstlane(int(d[0])));
-  if (chunk == 0u) return true;
   uint32_t const item = uint32_t(__builtin_amdgcn_readfirstlane(int(d[1])));
-  uint32_t done = 0;
-  if (lane == 0) done = __hip_atomic_load(&kargs(Pk)->tileDone[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  done = uint32_t(__builtin_amdgcn_readfirstlane(int(done)));
-  return done >= chunk;
+  uint32_t const slab = uint32_t(__builtin_amdgcn_readfirstlane(int(d[7])));
+  uint32_t const slabBit = 1u << (slab - wave_index(gtid) * kSlabsPerWave);
+  if (chunk > 0u) {
+    // Is the previous chunk in the film already (the usual case when the frame has more tiles than resident waves)?
+    // Then this wave folds, and nothing has to be published.  A stale "no" only costs an unnecessary publish.
+    uint32_t seen = 0;
+    if (lane == 0) seen = __hip_atomic_load(&T.link[size_t(chunk) * T.numItems + item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    seen = uint32_t(__builtin_amdgcn_readfirstlane(int(seen)));
+    if (seen != kFoldReady) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own staging stores have landed (in this XCD's L2)
+      slab_publish(T, lane, slab, chunk_samples(T, chunk));
+      if (lane == 0) __hip_atomic_store(&T.slabBusy[slab], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slab is in memory and marked busy -> offer it
+      uint32_t old = 0;
+      if (lane == 0) old = __hip_atomic_exchange(&T.link[size_t(chunk) * T.numItems + item], slab + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = uint32_t(__builtin_amdgcn_readfirstlane(int(old)));
+      if (old != kFoldReady) {  // the previous chunk is not in the film yet: its folder takes this slab
+        W.slabPend |= slabBit;
+        sched_count(kargs(Pk)->schedDiag, lane, SD_HANDED);
+        return;
+      }
+    }  // (kFoldReady seen or received: nobody else touches this word any more)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own staging stores have landed
+  fold_chain(T, kargs(Pk)->schedDiag, gtid, lane, item, chunk, slab);
+  W.slabFree |= slabBit;
 }
 
-DMT_DEV bool sched_begin(KArgs Pk, int lane, WaveSched& W) {
+DMT_DEV bool sched_begin(KArgs Pk, uint32_t gtid, int lane, WaveSched& W) {
   uint32_t units = 0;
-  if (!item_fetch(Pk, lane, 0u, units)) return false;
+  if (!item_fetch(Pk, gtid, lane, 0u, W, units)) return false;
   W.fetched = 1, W.alloc = 0, W.nextUnit = 0, W.totalUnits = units;
   return true;
 }
 
 // Hand the next units of the wave's items to the lanes that ask for one (`want`) and prepare them.
-DMT_DEV void sched_draw(KArgs Pk, int lane, WaveSched& W, LaneSched& Ls, bool want) {
+DMT_DEV void sched_draw(KArgs Pk, uint32_t gtid, int lane, WaveSched& W, LaneSched& Ls, bool want) {
   if (W.nextUnit == W.totalUnits) {  // item `alloc` is used up: move to the next one, fetching it if there is room
-    if (W.alloc + 1u == W.fetched && !W.exhausted && W.fetched - W.cur < 2u) {
+    if (W.alloc + 1u == W.fetched && !W.exhausted && W.fetched - W.cur < 2u && W.slabFree != 0u) {
       uint32_t units = 0;
-      if (item_fetch(Pk, lane, W.fetched, units)) ++W.fetched, ++W.alloc, W.nextUnit = 0, W.totalUnits = units;
+      if (item_fetch(Pk, gtid, lane, W.fetched, W, units)) ++W.fetched, ++W.alloc, W.nextUnit = 0, W.totalUnits = units;
       else W.exhausted = true;
     }
   }
@@ -919,13 +1032,35 @@ DMT_DEV void sched_draw(KArgs Pk, int lane, WaveSched& W, LaneSched& Ls, bool wa
   W.nextUnit += cnt < avail ? cnt : avail;
 }
 
-// item cur: all units drawn and none of them still in a lane -> fold it; false = the wave has no work left
+// item cur: all units drawn and none of them still in a lane -> complete it; false = the wave is done
 DMT_DEV bool sched_retire(KArgs Pk, uint32_t gtid, int lane, WaveSched& W) {
-  item_fold(Pk, gtid, lane, W.cur);
+  item_complete(Pk, gtid, lane, W.cur, W);
   ++W.cur;
+  if (W.slabPend != 0u) slab_refresh(load_tile_args(Pk), gtid, lane, W);  // once per completed item: which handed-over slabs are back?
   if (W.cur == W.fetched) {  // no live item
+    if (W.exhausted) return false;
+    if (W.slabFree == 0u) {
+      // Every slab of this wave is handed over and waits for a folder.  The wave holds nothing anybody needs; in a
+      // healthy launch a slab comes back within one item's tracing time.  Poll for a bounded WALL CLOCK time, then leave:
+      // the other waves fetch the remaining items, and a free wave slot lets a switched-out wave run again.
+      TileArgs const T = load_tile_args(Pk);
+      unsigned long long* const D = kargs(Pk)->schedDiag;
+      sched_count(D, lane, SD_STALLS);
+      unsigned long long const t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+      unsigned long long waited = 0;
+      do {
+        __builtin_amdgcn_s_sleep(64);
+        slab_refresh(T, gtid, lane, W);
+        waited = __builtin_amdgcn_s_memrealtime() - t0;
+      } while (W.slabFree == 0u && waited <= (unsigned long long)(DMT_SLAB_WAIT_MS) * 100000ull);
+      if (lane == 0) atomicMax(&D[SD_MAXSTALL], waited);
+      if (W.slabFree == 0u) {
+        sched_count(D, lane, SD_EXITS);
+        return false;
+      }
+    }
     uint32_t units = 0;
-    if (W.exhausted || !item_fetch(Pk, lane, W.fetched, units)) return false;
+    if (!item_fetch(Pk, gtid, lane, W.fetched, W, units)) return false;
     ++W.fetched, W.alloc = W.cur, W.nextUnit = 0, W.totalUnits = units;
   }
   return true;
@@ -968,16 +1103,16 @@ DMT_DEV void megakernel_body() {
   WaveSched W;
   LaneSched Ls;
   PathState st{};
-  auto sink = [&](f3 L, uint32_t sidx) { stage_sample(Pk, gtid, sidx, L); };
+  auto sink = [&](f3 L, uint32_t sidx) { stage_sample(Pk, sidx, L); };
 #if DMT_SECTION_TIMING
   if (lane < 16) s_sectAcc[threadIdx.x >> 6][lane] = 0;
   sect_mark(15);
 #endif
-  if (sched_begin(Pk, lane, W)) {
+  if (sched_begin(Pk, gtid, lane, W)) {
     for (;;) {
       bool const needPrep = !Ls.prepared;
       bool const starving = !st.active && needPrep;
-      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) sched_draw(Pk, lane, W, Ls, needPrep);
+      if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) sched_draw(Pk, gtid, lane, W, Ls, needPrep);
       if (!st.active && Ls.prepared) {
         path_begin_prepared(st);
         Ls.prepared = false;
@@ -986,15 +1121,10 @@ DMT_DEV void megakernel_body() {
       sect_mark(0);
       if (W.alloc != W.cur || W.nextUnit == W.totalUnits) {  // item cur has no units left: is it complete?
         if (!__any(lane_holds(st, Ls, (W.cur & 1u) != 0u))) {
-          // fold it now if the tile's previous chunk is in the film; otherwise keep tracing the other item
-          // meanwhile (matters when a GPU has fewer tiles than resident waves: 1/8 of a 1024^2 frame)
-          bool const busy = __any(st.active || st.hasShadow);
-          if (!busy || fold_ready(Pk, lane, W.cur)) {
-            bool const more = sched_retire(Pk, gtid, lane, W);
-            sect_mark(1);
-            if (!more) break;
-            continue;
-          }
+          bool const more = sched_retire(Pk, gtid, lane, W);  // fold it, or hand it over (never waits for another wave's item)
+          sect_mark(1);
+          if (!more) break;
+          continue;
         }
       }
       sect_mark(1);
@@ -1036,7 +1166,7 @@ DMT_DEV void megakernel_body_bvh() {
   WaveSched W;
   LaneSched Ls;
   PathState st{};
-  auto sink = [&](f3 L, uint32_t sidx) { stage_sample(Pk, gtid, sidx, L); };
+  auto sink = [&](f3 L, uint32_t sidx) { stage_sample(Pk, sidx, L); };
   Traversal tv{};
   tv.phase = TR_IDLE;
   {
@@ -1045,7 +1175,7 @@ DMT_DEV void megakernel_body_bvh() {
     tv.stack.stride = bvh0.overflowStride;
     if constexpr (STATS) tv.stack.ovfCount = &ls.tc.overflowPushes;
   }
-  if (sched_begin(Pk, lane, W)) {
+  if (sched_begin(Pk, gtid, lane, W)) {
     for (;;) {
       // A. draw + prepare units, start samples (only lanes between rounds start one)
       bool const idle = tv.phase == TR_IDLE;
@@ -1053,7 +1183,7 @@ DMT_DEV void megakernel_body_bvh() {
       bool const starving = idle && !st.active && needPrep;
       if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) {
         if constexpr (STATS) ++ls.itPrep, ls.lanesPrep += needPrep ? 1u : 0u;
-        sched_draw(Pk, lane, W, Ls, needPrep);
+        sched_draw(Pk, gtid, lane, W, Ls, needPrep);
       }
       if constexpr (STATS) ++ls.itOuter;
       if (idle && !st.active && Ls.prepared) {
@@ -1078,11 +1208,8 @@ DMT_DEV void megakernel_body_bvh() {
       // R. item cur has no units left: is it complete?
       if (W.alloc != W.cur || W.nextUnit == W.totalUnits) {
         if (!__any(lane_holds(st, Ls, (W.cur & 1u) != 0u))) {
-          bool const busy = __any(tv.phase != TR_IDLE);
-          if (!busy || fold_ready(Pk, lane, W.cur)) {  // see megakernel_body
-            if (!sched_retire(Pk, gtid, lane, W)) break;
-            continue;
-          }
+          if (!sched_retire(Pk, gtid, lane, W)) break;
+          continue;
         }
       }
       // C. traversal.  Lanes sit on an inner node, on a leaf, or have finished their ray.  Each iteration runs ONE
@@ -1477,11 +1604,13 @@ struct dmt_ctx {
   float4* d_m2 = nullptr;
   bool ownFilm = false;
   int filmW = 0, filmH = 0;
-  uint32_t* d_counter = nullptr;   // [0] work counter, [1] error flag
-  uint32_t* d_tileDone = nullptr;  // per owned tile: chunks completed (in-launch ordering)
-  float* d_stage = nullptr;        // staging of finished samples, [wave][chunkSpp][64] float3
+  uint32_t* d_counter = nullptr;   // work counter
+  uint32_t* d_sched = nullptr;     // [waves * kSlabsPerWave] slab-busy marks, then [numChunks][numItems] hand-over words; zeroed per launch
+  unsigned long long* d_schedDiag = nullptr;  // kSchedDiagWords counters over all launches (dmt_sched_diag)
+  unsigned long long expectedFolds = 0;       // work items launched so far: what d_schedDiag[0] must read once the stream has drained
+  float* d_stage = nullptr;        // staging slabs of finished samples, [wave][kSlabsPerWave][chunkSpp][64] float3
   size_t stageFloats = 0;
-  size_t tileDoneCap = 0;
+  size_t schedCap = 0;
   uint32_t chunkSpp = 0;           // samples per work item, 0 = automatic
   int subShift = -1;               // row bands per tile (log2); -1 = choose per launch
   int maxDepth = 32;
@@ -1747,14 +1876,18 @@ struct Scratch {
 #define SCRATCH_CHECK(ctx, p) \
   if (!(p)) return fail(ctx, DMT_ERR_HIP, "scratch allocation / upload failed")
 
-// After the stream has drained: has any wave of a past launch given up waiting for a tile's previous sample chunk
-// (item_fold)?  Then the film is not the ordered fold the contract promises.  Reads and clears the flag.
+// After the stream has drained: every work item of every past launch must have been folded into the film exactly once
+// (item_complete / fold_chain count their folds).  Anything else means the hand-over protocol lost or duplicated a sample
+// chunk and the film is not the ordered fold the contract promises.
 int checkErrorFlag(dmt_ctx* ctx) {
-  uint32_t flag = 0;
-  HIP_TRY(ctx, hipMemcpy(&flag, ctx->d_counter + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
-  if (flag) {
-    (void)hipMemset(ctx->d_counter + 1, 0, sizeof(uint32_t));
-    return fail(ctx, DMT_ERR_HIP, "a wave gave up waiting for a tile's previous sample chunk (in-launch ordering): the film is invalid");
+  unsigned long long folds = 0;
+  HIP_TRY(ctx, hipMemcpy(&folds, ctx->d_schedDiag, sizeof(folds), hipMemcpyDeviceToHost));
+  if (folds != ctx->expectedFolds) {
+    char msg[200];
+    snprintf(msg, sizeof(msg), "in-launch ordering: %llu sample chunks were folded into the film, %llu were launched: the film is invalid",
+             folds, ctx->expectedFolds);
+    ctx->expectedFolds = folds;  // report once
+    return fail(ctx, DMT_ERR_HIP, msg);
   }
   return DMT_OK;
 }
@@ -1792,6 +1925,8 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_ordinal);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_counter), 2 * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(ctx->d_counter, 0, 2 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->d_schedDiag), kSchedDiagWords * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(ctx->d_schedDiag, 0, kSchedDiagWords * sizeof(unsigned long long));
   int bpc = 0;
   if (e == hipSuccess)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, reinterpret_cast<void const*>(k_megakernel), 256, 0);
@@ -1838,7 +1973,8 @@ int dmt_ctx_destroy(dmt_ctx* ctx) {
   (void)hipFree(ctx->d_lights);
   (void)hipFree(ctx->d_inf);
   (void)hipFree(ctx->d_counter);
-  (void)hipFree(ctx->d_tileDone);
+  (void)hipFree(ctx->d_sched);
+  (void)hipFree(ctx->d_schedDiag);
   (void)hipFree(ctx->d_stage);
   (void)hipFree(ctx->d_env);
   (void)hipFree(ctx->d_areaOf);
@@ -2249,14 +2385,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   P.numChunks = (spp + P.chunkSpp - 1) / P.chunkSpp;
   if (uint64_t(P.numItems) * P.numChunks > 0x7FFFFFFFull)
     return fail(ctx, DMT_ERR_INVALID, "dmt_render: too many work items (tiles x sample chunks); raise dmt_set_chunk or split the pass");
-  if (size_t(P.numItems) > ctx->tileDoneCap) {
-    if (ctx->d_tileDone) (void)hipFree(ctx->d_tileDone);
-    ctx->d_tileDone = nullptr, ctx->tileDoneCap = 0;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_tileDone), size_t(P.numItems) * sizeof(uint32_t)));
-    ctx->tileDoneCap = P.numItems;
-  }
-  P.tileDone = ctx->d_tileDone;
-  P.errorFlag = ctx->d_counter + 1;
+  P.schedDiag = ctx->d_schedDiag;
 
   bool const useBvh = ctx->accel == DMT_ACCEL_BVH;
   uint32_t const wavesWanted = P.numItems * P.numChunks < P.numItems ? P.numItems : P.numItems * P.numChunks;
@@ -2286,8 +2415,8 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
     ctx->events.emplace_back(a, b);
   }
   auto& ev = ctx->events[ctx->eventsUsed];
-  {  // staging area of finished samples, one slab per wave of the launch
-    size_t const floats = size_t(blocks) * 4u * 2u * size_t(P.chunkSpp) * 192u;
+  {  // staging slabs of finished samples, kSlabsPerWave per wave of the launch
+    size_t const floats = size_t(blocks) * 4u * size_t(kSlabsPerWave) * size_t(P.chunkSpp) * 192u;
     if (floats > ctx->stageFloats) {
       if (ctx->d_stage) (void)hipFree(ctx->d_stage);
       ctx->d_stage = nullptr, ctx->stageFloats = 0;
@@ -2296,9 +2425,21 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
     }
     P.stage = ctx->d_stage;
   }
+  {  // slab-busy marks + one hand-over word per (chunk, tile item), all zero at launch
+    size_t const busyWords = size_t(blocks) * 4u * size_t(kSlabsPerWave);
+    size_t const linkWords = P.numChunks > 1 ? size_t(P.numItems) * size_t(P.numChunks) : 0;
+    if (busyWords + linkWords > ctx->schedCap) {
+      if (ctx->d_sched) (void)hipFree(ctx->d_sched);
+      ctx->d_sched = nullptr, ctx->schedCap = 0;
+      HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_sched), (busyWords + linkWords) * sizeof(uint32_t)));
+      ctx->schedCap = busyWords + linkWords;
+    }
+    P.slabBusy = ctx->d_sched, P.link = ctx->d_sched + busyWords;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_sched, 0, (busyWords + linkWords) * sizeof(uint32_t), ctx->stream));
+  }
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(uint32_t), ctx->stream));
-  if (P.numChunks > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->d_tileDone, 0, size_t(P.numItems) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream));
+  uint64_t const launchFolds = uint64_t(P.numItems) * P.numChunks;  // every item is folded exactly once (checkErrorFlag)
   if (useBvh && wavefront) {
     if (!ctx->haveBvh) return fail(ctx, DMT_ERR_STATE, "dmt_render: BVH not built");
     int const rcW = launchWavefront(ctx, P, ownedTiles, sample_offset, spp, useEnv, useArea, stats6, nstats);
@@ -2319,6 +2460,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
       else
         hipLaunchKernelGGL(k_megakernel_bvh_stats, dim3(blocks), dim3(256), 0, ctx->stream, P);
       hipError_t e = hipGetLastError();
+      if (e == hipSuccess) ctx->expectedFolds += launchFolds;
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
       if (e == hipSuccess) e = hipMemcpy(stats6, dstats, size_t(nstats) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
       (void)hipFree(dstats);
@@ -2330,6 +2472,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
     hipLaunchKernelGGL(megakernelOf(ctx), dim3(blocks), dim3(256), 0, ctx->stream, P);
   }
   HIP_TRY(ctx, hipGetLastError());
+  if (!(useBvh && wavefront)) ctx->expectedFolds += launchFolds;
   HIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream));
   ++ctx->eventsUsed;
   return DMT_OK;
@@ -2432,6 +2575,22 @@ int dmt_sync(dmt_ctx* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return checkErrorFlag(ctx);
+}
+
+int dmt_sched_diag(dmt_ctx* ctx, uint64_t* out8, int reset) {
+  if (!ctx || !out8) return DMT_ERR_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long d[kSchedDiagWords] = {};
+  HIP_TRY(ctx, hipMemcpy(d, ctx->d_schedDiag, sizeof(d), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 8; ++i) out8[i] = i < kSchedDiagWords ? d[i] : 0;
+  out8[6] = ctx->expectedFolds;
+  out8[7] = uint64_t(kSlabsPerWave);
+  if (reset) {
+    HIP_TRY(ctx, hipMemset(ctx->d_schedDiag, 0, sizeof(d)));
+    ctx->expectedFolds = 0;
+  }
+  return DMT_OK;
 }
 
 // (re)builds the per-triangle lookup from the host copy of the area-light list

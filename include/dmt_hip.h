@@ -153,7 +153,7 @@ int dmt_film_clear(dmt_ctx* ctx);
 /* use caller-owned device buffers (width*height float4 each) instead of the context's own */
 int dmt_film_bind(dmt_ctx* ctx, void* d_mean, void* d_m2);
 int dmt_film_device_ptrs(dmt_ctx* ctx, void** d_mean, void** d_m2);
-/* synchronises the stream; DMT_ERR_HIP (and no copy) if a wave of a past launch gave up its ordered fold (see dmt_sync) */
+/* synchronises the stream; DMT_ERR_HIP (and no copy) if a past launch did not fold every sample chunk exactly once (see dmt_sync) */
 int dmt_download_film(dmt_ctx* ctx, float* mean4, float* m24);
 
 /* ---- render -------------------------------------------------------------------------------- */
@@ -172,10 +172,15 @@ int dmt_render_stats(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0,
  * went to the global overflow area (entries beyond the LDS part of the stack). */
 int dmt_render_profile(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0, int y0, int x1, int y1,
                        uint64_t* stats16);
-/* waits for the stream; DMT_ERR_HIP if any wave gave up waiting for a tile's previous sample chunk (the in-launch
- * ordering that makes the film schedule-independent): the film is then invalid.  dmt_download_film and dmt_kernel_time
- * report the same condition. */
+/* waits for the stream; DMT_ERR_HIP if the launches so far did not fold every (tile, sample chunk) into the film exactly
+ * once (the in-launch hand-over that makes the film schedule-independent counts its folds): the film is then invalid.
+ * dmt_download_film and dmt_kernel_time report the same condition. */
 int dmt_sync(dmt_ctx* ctx);
+/* Diagnostics of the in-launch fold hand-over, accumulated over the launches since the last reset (synchronises):
+ * out8 = {sample chunks folded, chunks handed over to the folder of their predecessor, chunks folded on behalf of another
+ * wave, times a wave found all its staging slabs handed over, waves that left the launch early because of that,
+ * longest such stall in 10 ns ticks, sample chunks launched (must equal [0]), staging slabs per wave}. */
+int dmt_sched_diag(dmt_ctx* ctx, uint64_t* out8, int reset);
 /* HIP-event time of the megakernel launches since the last reset (synchronises the stream):
  * total milliseconds and launch count. */
 int dmt_kernel_time(dmt_ctx* ctx, double* total_ms, uint64_t* launches, int reset);

@@ -392,7 +392,7 @@ def test_concurrent_contexts_partition_is_exact(renderer, pkg, O, accel):
             for ctx in ranks:                      # asynchronous launches on W different streams
                 ctx.render(spp, sample_offset=k * spp)
         for ctx in ranks:
-            ctx.sync()                             # raises if any wave gave up its ordered fold
+            ctx.sync()                             # raises unless every sample chunk was folded exactly once
         parts = [ctx.download_film() for ctx in ranks]
     finally:
         for ctx in ranks:
@@ -630,7 +630,7 @@ def test_row_band_scheduling_is_bit_exact(pkg, O, monkeypatch):
 
 
 def test_sample_chunking_is_bit_exact(renderer, O):
-    """In-launch sample chunks (work items = tile x chunk, ordered per tile by release/acquire counters)
+    """In-launch sample chunks (work items = tile x chunk, folded in chunk order per tile through the hand-over words)
     are a scheduling knob only: any chunk size gives the same film bits as one item per tile."""
     _load_cornell(renderer, O, 200, 136, 8)
     films = []
@@ -644,6 +644,40 @@ def test_sample_chunking_is_bit_exact(renderer, O):
     for f in films[1:]:
         assert np.array_equal(films[0][0], f[0]) and np.array_equal(films[0][1], f[1])
     assert np.all(films[0][1][..., 3] == 96)
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+def test_fold_handover_small_frame(renderer, pkg, O, accel):
+    """The ordered fold without waiting (dmt_hip.hip: item_complete / fold_chain).  A 64 x 64 frame is 64 tiles for ~4 000
+    resident waves, so with 1-sample chunks hundreds of chunks of every tile are traced at the same time and finish out
+    of order: most of them are HANDED OVER to the wave that folds their predecessor, which folds them in a chain.  The
+    film must equal the one-item-per-tile film bit for bit, every launched chunk must be folded exactly once, and no wave
+    may have left the launch for want of a staging slab."""
+    w, h, spp = 64, 64, 256
+    scene = O.cornell_box(w, h) if accel == 0 else pkg.host_scene.random_triangle_scene(3000, width=w, height=h)
+    renderer.upload_scene(scene)
+    renderer.set_limits(8)
+    renderer.set_accel(accel)
+    renderer.set_chunk(1000)                   # one item per tile: no hand-over word is ever used
+    renderer.film_clear()
+    renderer.sched_diag(reset=True)
+    renderer.render(spp)
+    ref = renderer.download_film()
+    d0 = renderer.sched_diag(reset=True)
+    assert d0["handed_over"] == 0 and d0["folds"] == d0["launched"]
+    for chunk in (1, 2, 5):
+        renderer.set_chunk(chunk)
+        renderer.film_clear()
+        renderer.render(spp)
+        got = renderer.download_film()
+        d = renderer.sched_diag(reset=True)
+        assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1]), chunk
+        assert d["folds"] == d["launched"] > 0, d
+        assert d["handed_over"] > d["launched"] // 4, d       # the hand-over path really ran ...
+        assert d["folded_for_others"] == d["handed_over"], d  # ... and every handed-over chunk was folded by a chain
+        assert d["early_exits"] == 0, d
+    renderer.set_chunk(0)
+    renderer.set_accel(0)
 
 
 def test_cli_writes_reference_named_pngs(renderer, O, tmp_path):
