@@ -251,7 +251,7 @@ inline void encodeNode(Bvh4Node& nd, Box const* kid, int nk, int nInner) {
   uint32_t* const qhi[3] = {&nd.qhix, &nd.qhiy, &nd.qhiz};
   for (int k = 0; k < 4; ++k)
     for (int a = 0; a < 3; ++a) {
-      uint32_t l = 255, h = 0;  // empty slot: inverted box (and masked by count on the device)
+      uint32_t l = 255, h = 0;  // empty slot: inverted box; NOT masked by count on the device -- see buildBvh's guard pairs
       if (k < nk) {
         double const fl = std::floor((double(kid[k].lo[a]) - double(org[a])) / scale[a]);
         double const fh = std::ceil((double(kid[k].hi[a]) - double(org[a])) / scale[a]);

@@ -180,9 +180,10 @@ DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc =
   uint32_t const nqy = tv.sr.negy ? w2.y : w2.x, fqy = tv.sr.negy ? w2.x : w2.y;
   uint32_t const nqz = tv.sr.negz ? w2.w : w2.z, fqz = tv.sr.negz ? w2.z : w2.w;
   // An empty slot holds the inverted box (lo 255, hi 0): on every axis with a finite slope its near plane lies a whole
-  // 255 * |a| behind its far plane, so it misses by itself (the builder keeps every scale >= 2^-60, so a never
-  // flushes to zero).  No widening of the exit distance either: the builder's padding exceeds the slab arithmetic's
-  // rounding by more than an order of magnitude (header).
+  // 255 * |a| behind its far plane, so it misses by itself -- unless 255 * |a| vanishes against |b| in fp32 on every axis
+  // that has a finite slope (axis-parallel ray, node flat on the other axes).  Then the slot "hits" and its implicit
+  // reference names a pair of the next node, or one of the three guard pairs behind the array (buildBvh): a real
+  // triangle is tested once more, no result changes, nothing is read out of bounds.  Cheaper than four compares per step.
   uint32_t k0, k1, k2, k3;
   slab_keys<0, 1>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, k0, k1);
   slab_keys<2, 3>(nqx, nqy, nqz, fqx, fqy, fqz, a, b, tlimit, k2, k3);

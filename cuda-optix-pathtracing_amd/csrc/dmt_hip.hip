@@ -805,7 +805,7 @@ DMT_DEV uint32_t chunk_samples(TileArgs const& T, uint32_t chunk) {
 
 // index of this wave in the launch, as a value the compiler knows to be wave-uniform (gtid >> 6 lives in a VGPR; slab
 // bookkeeping derived from it would be treated as divergent: VALU bit scans, exec-masked branches around item_fetch)
-DMT_DEV uint32_t wave_index(uint32_t gtid) { return uint32_t(__builtin_amdgcn_readfirstlane(int(gtid >> 6))); }
+DMT_DEV uint32_t wave_index(uint32_t) { return blockIdx.x * (kLdsThreads / 64) + uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))); }
 
 // which of the wave's handed-over slabs have been folded meanwhile?
 DMT_DEV void slab_refresh(TileArgs const& T, uint32_t gtid, int lane, WaveSched& W) {
@@ -1007,19 +1007,14 @@ DMT_DEV void item_complete(KArgs Pk, uint32_t gtid, int lane, uint32_t seq, Wave
   W.slabFree |= slabBit;
 }
 
-DMT_DEV bool sched_begin(KArgs Pk, uint32_t gtid, int lane, WaveSched& W) {
-  uint32_t units = 0;
-  if (!item_fetch(Pk, gtid, lane, 0u, W, units)) return false;
-  W.fetched = 1, W.alloc = 0, W.nextUnit = 0, W.totalUnits = units;
-  return true;
-}
-
-// Hand the next units of the wave's items to the lanes that ask for one (`want`) and prepare them.
+// Hand the next units of the wave's items to the lanes that ask for one (`want`) and prepare them.  This is the ONE place
+// where work items are fetched (item_fetch is large, and the kernel already fills most of the instruction cache): a wave
+// starts with no item, and a wave whose last live item was retired comes here because all its lanes are starving.
 DMT_DEV void sched_draw(KArgs Pk, uint32_t gtid, int lane, WaveSched& W, LaneSched& Ls, bool want) {
-  if (W.nextUnit == W.totalUnits) {  // item `alloc` is used up: move to the next one, fetching it if there is room
-    if (W.alloc + 1u == W.fetched && !W.exhausted && W.fetched - W.cur < 2u && W.slabFree != 0u) {
+  if (W.nextUnit == W.totalUnits) {  // the item units are drawn from is used up (or there is none yet): fetch the next if there is room
+    if (!W.exhausted && W.fetched - W.cur < 2u && W.slabFree != 0u) {
       uint32_t units = 0;
-      if (item_fetch(Pk, gtid, lane, W.fetched, W, units)) ++W.fetched, ++W.alloc, W.nextUnit = 0, W.totalUnits = units;
+      if (item_fetch(Pk, gtid, lane, W.fetched, W, units)) W.alloc = W.fetched, ++W.fetched, W.nextUnit = 0, W.totalUnits = units;
       else W.exhausted = true;
     }
   }
@@ -1032,12 +1027,12 @@ DMT_DEV void sched_draw(KArgs Pk, uint32_t gtid, int lane, WaveSched& W, LaneSch
   W.nextUnit += cnt < avail ? cnt : avail;
 }
 
-// item cur: all units drawn and none of them still in a lane -> complete it; false = the wave is done
+// item cur: all units drawn and none of them still in a lane -> complete it; false = the wave leaves the launch
 DMT_DEV bool sched_retire(KArgs Pk, uint32_t gtid, int lane, WaveSched& W) {
   item_complete(Pk, gtid, lane, W.cur, W);
   ++W.cur;
   if (W.slabPend != 0u) slab_refresh(load_tile_args(Pk), gtid, lane, W);  // once per completed item: which handed-over slabs are back?
-  if (W.cur == W.fetched) {  // no live item
+  if (W.cur == W.fetched) {  // no live item: the next sched_draw fetches one
     if (W.exhausted) return false;
     if (W.slabFree == 0u) {
       // Every slab of this wave is handed over and waits for a folder.  The wave holds nothing anybody needs; in a
@@ -1059,9 +1054,6 @@ DMT_DEV bool sched_retire(KArgs Pk, uint32_t gtid, int lane, WaveSched& W) {
         return false;
       }
     }
-    uint32_t units = 0;
-    if (!item_fetch(Pk, gtid, lane, W.fetched, W, units)) return false;
-    ++W.fetched, W.alloc = W.cur, W.nextUnit = 0, W.totalUnits = units;
   }
   return true;
 }
@@ -1108,11 +1100,12 @@ DMT_DEV void megakernel_body() {
   if (lane < 16) s_sectAcc[threadIdx.x >> 6][lane] = 0;
   sect_mark(15);
 #endif
-  if (sched_begin(Pk, gtid, lane, W)) {
+  {
     for (;;) {
       bool const needPrep = !Ls.prepared;
       bool const starving = !st.active && needPrep;
       if (__any(starving) || __popcll(__ballot(needPrep)) >= DMT_PREP_THRESHOLD) sched_draw(Pk, gtid, lane, W, Ls, needPrep);
+      if (W.cur == W.fetched) break;  // nothing live and nothing fetched: the launch has no more items
       if (!st.active && Ls.prepared) {
         path_begin_prepared(st);
         Ls.prepared = false;
@@ -1175,7 +1168,7 @@ DMT_DEV void megakernel_body_bvh() {
     tv.stack.stride = bvh0.overflowStride;
     if constexpr (STATS) tv.stack.ovfCount = &ls.tc.overflowPushes;
   }
-  if (sched_begin(Pk, gtid, lane, W)) {
+  {
     for (;;) {
       // A. draw + prepare units, start samples (only lanes between rounds start one)
       bool const idle = tv.phase == TR_IDLE;
@@ -1185,6 +1178,7 @@ DMT_DEV void megakernel_body_bvh() {
         if constexpr (STATS) ++ls.itPrep, ls.lanesPrep += needPrep ? 1u : 0u;
         sched_draw(Pk, gtid, lane, W, Ls, needPrep);
       }
+      if (W.cur == W.fetched) break;  // nothing live and nothing fetched: the launch has no more items
       if constexpr (STATS) ++ls.itOuter;
       if (idle && !st.active && Ls.prepared) {
         path_begin_prepared(st);
@@ -1809,7 +1803,13 @@ int buildBvh(dmt_ctx* ctx) {
   // (CC/private/shapes.cu:10-11) in IEEE fp32.
   size_t const npairs = r.pairTris.size() / 2;
   if (npairs > 0x7FFFFFFFull || r.nodes.size() > 0x7FFFFFFFull) return fail(ctx, DMT_ERR_INVALID, "BVH: too many nodes / triangle pairs");
-  std::vector<TriPair> pairs(npairs);
+  // + 3 guard pairs (copies of the last one).  An EMPTY child slot holds an inverted quantised box and no reference of its
+  // own; its slab test misses by itself except in one corner: a ray exactly parallel to an axis through a node that is flat
+  // on the remaining axes (255 quantisation steps below half an ulp of the plane distance), where near == far.  The slot's
+  // implicit reference is then leafBase + slot - inner, i.e. a pair of the NEXT node -- or, for the last node, up to three
+  // pairs past the array.  Testing some real triangle of the scene once more changes no result (the triangle test decides
+  // hits, and a scene triangle is a scene triangle); reading past the array would, hence the guards.
+  std::vector<TriPair> pairs(npairs ? npairs + 3 : 0);
   for (size_t p = 0; p < npairs; ++p)
     for (int half = 0; half < 2; ++half) {
       uint32_t const i = r.pairTris[2 * p + size_t(half)];
@@ -1822,6 +1822,7 @@ int buildBvh(dmt_ctx* ctx) {
       P.e1x[half] = xs[2] - xs[0], P.e1y[half] = ys[2] - ys[0], P.e1z[half] = zs[2] - zs[0];
       P.orig[half] = i;
     }
+  for (size_t p = npairs; p < pairs.size(); ++p) pairs[p] = pairs[npairs - 1];
   int rc = devAlloc(ctx, &ctx->d_bvhNodes, r.nodes.size());
   if (rc) return rc;
   rc = devAlloc(ctx, &ctx->d_trisBvh, pairs.size());
@@ -1831,7 +1832,7 @@ int buildBvh(dmt_ctx* ctx) {
     HIP_TRY(ctx, hipMemcpy(ctx->d_trisBvh, pairs.data(), pairs.size() * sizeof(TriPair), hipMemcpyHostToDevice));
   ctx->bvhDepth = r.depth;
   ctx->bvhNodeCount = uint32_t(r.nodes.size());
-  ctx->bvhPairCount = uint32_t(pairs.size());
+  ctx->bvhPairCount = uint32_t(npairs);
   ctx->haveBvh = true;
   return DMT_OK;
 }

@@ -36,14 +36,62 @@ def owned_pixel_mask(width, height, rank, world, region=None):
     return mask
 
 
-def combine_films(mean, m2, dst=0, film=None):
-    """SUM-reduce the two film planes (torch tensors, full frames, zero outside the owned tiles) to `dst`.
-    `film`: optionally the single tensor both planes are views of ([2, h, w, 4]); then one collective does it."""
+def pack_owned_tiles(film, rank, world):
+    """[2, h, w, 4] film (h, w multiples of 8) -> [ceil(T / world), 512] tensor holding this rank's 8x8 tiles (both planes of a
+    tile side by side), in the order of owned_tiles(); the last row is zero padding when the tile count does not divide."""
+    import torch
+    _, h, w, _ = film.shape
+    th, tw = h // TILE, w // TILE
+    tiles = film.view(2, th, TILE, tw, TILE, 4).permute(1, 3, 0, 2, 4, 5).reshape(th * tw, 2 * TILE * TILE * 4)
+    per = (th * tw + world - 1) // world
+    mine = tiles[rank::world]
+    if mine.shape[0] == per:
+        return mine.contiguous()
+    out = torch.zeros((per, tiles.shape[1]), dtype=film.dtype, device=film.device)
+    out[:mine.shape[0]] = mine
+    return out
+
+
+def unpack_owned_tiles(film, packs):
+    """Inverse of pack_owned_tiles on the destination rank: packs[r] are rank r's tiles; writes them into `film` in place."""
+    _, h, w, _ = film.shape
+    th, tw = h // TILE, w // TILE
+    world = len(packs)
+    tiles = film.new_zeros((th * tw, 2 * TILE * TILE * 4))
+    for r, p in enumerate(packs):
+        n = tiles[r::world].shape[0]
+        tiles[r::world] = p[:n]
+    film.copy_(tiles.view(th, tw, 2, TILE, TILE, 4).permute(2, 0, 3, 1, 4, 5).reshape(2, h, w, 4))
+
+
+def combine_films(mean, m2, dst=0, film=None, mode=None):
+    """Bring every rank's owned tiles together on `dst`.  Two exact ways (the tile sets are disjoint):
+
+    * "reduce" (default): SUM-reduce of the zero-initialised full frames, x + 0 == x.  One collective, nothing to pack;
+      moves the whole frame per rank (RCCL ring: 2 (N-1)/N x frame bytes over the slowest link).
+    * "gather" (DMT_COMBINE=gather; SURVEY 8(e)-1's first choice): each rank packs only its own tiles and they are gathered
+      on `dst` (RCCL implements gather as grouped ncclSend / ncclRecv): 1/N of the bytes per rank, each over its own xGMI
+      link to `dst`.  Needs `film` = the [2, h, w, 4] tensor both planes are views of, with h and w multiples of 8.
+
+    Both leave the complete film on `dst`; tests/test_multigpu_cpu.py proves them bit-identical."""
+    import os
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        if film is not None:
-            dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
-        else:
-            dist.reduce(mean, dst=dst, op=dist.ReduceOp.SUM)
-            dist.reduce(m2, dst=dst, op=dist.ReduceOp.SUM)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return mean, m2
+    mode = mode or os.environ.get("DMT_COMBINE", "reduce")
+    if mode not in ("reduce", "gather"):
+        raise ValueError(f"DMT_COMBINE must be 'reduce' or 'gather', not {mode!r}")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if mode == "gather" and film is not None and film.shape[1] % TILE == 0 and film.shape[2] % TILE == 0:
+        pack = pack_owned_tiles(film, rank, world)
+        packs = [pack.new_empty(pack.shape) for _ in range(world)] if rank == dst else None
+        dist.gather(pack, packs, dst=dst)
+        if rank == dst:
+            unpack_owned_tiles(film, packs)
+        return mean, m2
+    if film is not None:
+        dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
+    else:
+        dist.reduce(mean, dst=dst, op=dist.ReduceOp.SUM)
+        dist.reduce(m2, dst=dst, op=dist.ReduceOp.SUM)
     return mean, m2

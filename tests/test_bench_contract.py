@@ -72,16 +72,19 @@ def test_roofline_record_on_every_path(name):
             pmc["SQ_ACTIVE_INST_VALU"] = 0.9 * b.SIMDS * ms * 1e-3 * 2.3e9 / 4
         r = b.build_roofline(name, stats, ms, samples, spp, pmc, {"vgprs": 128, "lds_bytes": 1, "blocks_per_cu": 4, "cu_count": 256})
         json.dumps(r)
-        assert r["bound"] == ("hbm" if bvh else "valu")
+        assert r["bound"] == ("valu_issue" if bvh else "valu")   # the bound the counters show
         assert r["frac"] is None or 0 <= r["frac"] <= 1.0
+        assert r["pmc_record"]["matches_loaded_library"] is False      # the synthetic record carries no library hash
         if bvh:
-            assert (r["frac"] is not None) == have_pmc and r["unit"] == "GB/s"
+            assert (r["frac"] is not None) == have_pmc and r["peak"] == 1.0
             if have_pmc:
-                assert abs(r["frac"] - 0.05) < 1e-3 and r["traffic"] == pmc["hbm_bytes_per_launch"]
+                assert abs(r["frac"] - 0.9) < 1e-3 and r["traffic"] == pmc["hbm_bytes_per_launch"]
+                assert abs(r["hbm_view"]["frac_of_spec_peak"] - 0.05) < 1e-3
         else:
             assert r["unit"] == "TFLOP/s" and (r["frac"] is not None) == (stats is not None)
             if stats is not None:
                 assert r["cache_level_rate"]["GB/s"] > b.HBM_PEAK_GBS       # the rate round 1 mislabelled as an HBM fraction
+                assert 0 < r["valu_view"]["frac_tests_only"] < r["valu_view"]["frac"]   # both FLOP models are reported
         if have_pmc:
             assert abs(r["issue_view"]["valu_busy"] - 0.9) < 1e-3
     # the Cornell workloads all have fallback counters (round 1: KeyError for the 4096^2 frame)
@@ -96,4 +99,20 @@ def test_json_line_keys_present_in_source():
         assert re.search(rf'"{key}"\s*:', src), key
     for key in ("bound", "achieved", "peak", "frac", "traffic", "cores", "kind", "sample", "cpu"):
         assert re.search(rf'"{key}"\s*:', src), key
-    assert "r.sync()" in src and "sys.exit(main())" in src      # a fold that gave up / a bad film fails the run
+    for key in ("secondary", "per_rank", "fold_handover", "kernel_ms_per_step", "combine_ms_per_step", "final_barrier_wait_ms"):
+        assert re.search(rf'"{key}"\s*:', src), key
+    assert "r.sync()" in src and "sys.exit(main())" in src      # a launch that lost a sample chunk / a bad film fails the run
+
+
+def test_issue_view_uses_the_cycles_of_its_own_pass():
+    """SQ_BUSY_CYCLES (shader cycles x 32 shader engines) of the same PMC pass is the denominator; a saturated pipe reads
+    slightly above 1 raw and clips to 1 (bench.py explains why)."""
+    b = _bench()
+    name = b.DEFAULT_WORKLOAD
+    pmc = {"kspp": 1024, "hbm_bytes_per_launch": 36.66e9, "SQ_ACTIVE_INST_VALU": 198412231802.0, "SQ_INSTS_VALU": 191378109987.0,
+           "SQ_BUSY_CYCLES": 23838067799.0, "kernel_ms": 314.5189, "clock_ghz": 2.0}
+    r = b.build_roofline(name, b.WORKLOAD_STATS[name], 312.3, 1024.0 ** 3, 1024, pmc)
+    iv = r["issue_view"]
+    assert abs(iv["raw"] - 1.0405) < 2e-3 and iv["valu_busy"] == 1.0 and abs(iv["clock_ghz"] - 2.3685) < 2e-3
+    assert abs(iv["valu_insts_x4_per_simd_cycle"] - 1.0036) < 2e-3
+    assert abs(r["valu_view"]["frac"] - 0.27) < 0.01 and abs(r["valu_view"]["frac_tests_only"] - 0.228) < 0.01

@@ -485,6 +485,35 @@ def test_bvh_closest_hit_equals_brute_force(renderer, O, ntri):
         assert ai.max() < 400 or (ai[ai >= 377] < 400).all()          # never the duplicate copy
 
 
+def test_bvh_empty_slots_axis_parallel_rays(renderer, O):
+    """A flat floor (one triangle pair -> a root with one leaf and three EMPTY slots) under rays exactly parallel to an
+    axis: the other two axes drop out of the slab test as NaN, and on the floor's flat axis 255 quantisation steps
+    vanish against the plane distance, so the inverted boxes of the empty slots "hit" (near == far).  Their implicit
+    references must stay inside the pair array (guard pairs) and the result must equal brute force."""
+    def tri(p0, p1, p2):
+        return [p0[0], p1[0], p2[0], 0.0], [p0[1], p1[1], p2[1], 0.0], [p0[2], p1[2], p2[2], 0.0]
+    for nfloor in (1, 2, 3):                                   # 1..3 triangles: the last node's leaves end the array
+        t = [tri((-1, 0, -1), (1, 0, -1), (1, 0, 1)), tri((-1, 0, -1), (1, 0, 1), (-1, 0, 1)), tri((2, 0, 2), (3, 0, 2), (3, 0, 3))][:nfloor]
+        xs = np.array([a[0] for a in t], np.float32).reshape(-1); ys = np.array([a[1] for a in t], np.float32).reshape(-1)
+        zs = np.array([a[2] for a in t], np.float32).reshape(-1)
+        renderer.upload_triangles(xs, ys, zs, np.zeros(nfloor, np.uint32))
+        g = np.linspace(-1.5, 3.5, 41, dtype=np.float32)
+        gx, gz = np.meshgrid(g, g)
+        n = gx.size
+        o = np.stack([gx.ravel(), np.full(n, 5.0, np.float32), gz.ravel()], axis=1).astype(np.float32)
+        d = np.tile(np.array([0.0, -1.0, 0.0], np.float32), (n, 1))
+        # the same from below, and rays along x / z skimming over the floor (miss) and in its plane
+        o = np.concatenate([o, o * np.array([1, -1, 1], np.float32), np.stack([np.full(n, -9.0, np.float32), gz.ravel() * 0, gx.ravel()], axis=1)])
+        d = np.concatenate([d, -d, np.tile(np.array([1.0, 0.0, 0.0], np.float32), (n, 1))])
+        renderer.set_accel(0)
+        bi, bt = renderer.test_closest_hit(o, d)
+        renderer.set_accel(1)
+        ai, at = renderer.test_closest_hit(o, d)
+        renderer.set_accel(0)
+        assert np.array_equal(ai, bi) and np.array_equal(at.view(np.uint32), bt.view(np.uint32))
+        assert (ai >= 0).sum() > 100
+
+
 def test_bvh_film_bit_exact_vs_brute_force(renderer, pkg, O):
     """Whole path tracer through the BVH == brute force, bit for bit (closest hits, shadow rays, ties)."""
     for scene, res, spp in ((pkg.host_scene.cornell_box(64, 64), 64, 16),

@@ -42,4 +42,4 @@ with pkg.Renderer(0) as r:
               f"{counts[3] / counts[2]:.1f}, GGX lanes per pass {counts[1] / counts[2]:.2f}")
     for k, name in enumerate(NAMES):
         if out[k]:
-            print(f"  {name:34s} {100.0 * out[k] / tot:6.2f} %")
+            print(f"  {name:34s} {100.0 * out[k] / tot:6.2f} %   {out[k] / 1e9:9.3f} G wave-cycles")

@@ -38,7 +38,11 @@ d = {k: sum(v) / len(v) for k, v in sorted(vals.items())}
 for k, v in d.items():
     print(f"{k:28s} {v:.6g}")
 
-rec = {"kspp": kspp, "kernel": kernel, "tag": tag, "samples_per_launch": samples_per_launch}
+import hashlib
+_so = ROOT / "cuda-optix-pathtracing_amd" / "csrc" / "libdmt_hip.so"
+lib_sha16 = (first.get("roofline", {}).get("pmc_record") or {}).get("loaded_lib_sha16") or \
+    (hashlib.sha256(_so.read_bytes()).hexdigest()[:16] if _so.exists() else None)
+rec = {"kspp": kspp, "kernel": kernel, "tag": tag, "samples_per_launch": samples_per_launch, "lib_sha16": lib_sha16}
 rec.update(d)
 ms = bench.get("sq1", first)["roofline"]["avg_launch_ms"]
 rec["kernel_ms"] = ms
@@ -51,7 +55,8 @@ if "SQ_WAVE_CYCLES" in d:
     rec["wait_inst_any_share"] = round(d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"], 4)
     rec["valu_insts_per_sample"] = round(d["SQ_INSTS_VALU"] / samples_per_launch, 2)
     clk = rec.get("clock_ghz", 2.4)
-    rec["valu_busy"] = round(d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * ms * 1e-3 * clk * 1e9), 4)
+    cycles = d["SQ_BUSY_CYCLES"] / 32.0 if d.get("SQ_BUSY_CYCLES") else ms * 1e-3 * clk * 1e9   # same pass (bench.py build_roofline)
+    rec["valu_busy"] = round(d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * cycles), 4)
 if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
     # gfx950: FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE reads HALF the bytes (MI355X_MICROARCH.md, HBM)
     rec["FETCH_SIZE_KiB"], rec["WRITE_SIZE_KiB"] = d["FETCH_SIZE"], d["WRITE_SIZE"]
