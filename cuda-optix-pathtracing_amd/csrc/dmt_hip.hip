@@ -276,6 +276,21 @@ DMT_DEV f3 tex_bilinear(KArgs k, int32_t tex, float s, float t, bool isNormal) {
   if (isNormal) c.x = c.x * 2.f - 1.f, c.y = c.y * 2.f - 1.f;
   return c;
 }
+// metallic fraction of a BS_GGX_BLEND material at the hit: the record's constant, or the material's 1-channel metallic map
+// (core-material.cpp:209-216), whose index sits in the first texture slot of the pair's SECOND row
+DMT_DEV float blend_metallic(KArgs k, Rec32 const& rec, uint32_t matId, int tri, float bu, float bv) {
+  KArgs const ka = kargs(k);
+  float m = h2f(lo16(rec.w[0]));
+  if (ka->matTex != nullptr) {
+    int32_t const texM = int32_t(ka->matTex[4 * (matId + 1u)]);
+    if (texM >= 0) {
+      float const* const uv = ka->triUv + 6 * size_t(tri);
+      float const w0 = 1.f - bu - bv;
+      m = tex_bilinear(k, texM, w0 * uv[0] + bu * uv[2] + bv * uv[4], w0 * uv[1] + bu * uv[3] + bv * uv[5], false).x;
+    }
+  }
+  return m;
+}
 // patches `rec` from the material's textures at the hit and returns the shading normal (ng when there is no normal map)
 DMT_DEV f3 apply_material_textures(KArgs k, Rec32& rec, uint32_t matId, int tri, float bu, float bv, f3 ng) {
   KArgs const ka = kargs(k);
@@ -320,7 +335,7 @@ DMT_DEV f3 apply_material_textures(KArgs k, Rec32& rec, uint32_t matId, int tri,
   return (l2 > 0.f && l2 < kInf) ? ns / sqrtf(l2) : ng;
 }
 
-template <bool ENV = false, bool AREA = false, bool TEX = false, bool LTREE = false>
+template <bool ENV = false, bool AREA = false, int TEX = false, bool LTREE = false>
 DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv) {
   SceneView const sc = load_scene(k);
   int const maxDepth = kargs(k)->maxDepth;
@@ -373,7 +388,26 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
   f3 const wo = -rd;
   Rec32 rec = sc.bsdfs[hit.matId];
   f3 ns = hit.normal;  // shading normal: the geometric one unless a normal map says otherwise
-  if constexpr (TEX) ns = apply_material_textures(k, rec, hit.matId, bestTri, bu, bv, hit.normal);
+  // fractional "metallic" (BS_GGX_BLEND, JSON scenes): both lobes of the material are prepared, evaluated and sampled and the
+  // results blended as the reference's CPU renderer does (core-material.cpp:275-286, :383-394).  TEX instantiations only.
+  Rec32 rec2{};
+  float mix = 0.f;
+  bool blend = false;
+  if constexpr (TEX >= 2) {
+    if (hi16(rec.w[1]) == BS_GGX_BLEND) {
+      mix = blend_metallic(k, rec, hit.matId, bestTri, bu, bv);
+      rec.w[1] = (rec.w[1] & 0x0000FFFFu) | (uint32_t(BS_GGX_DIEL) << 16);
+      rec2 = sc.bsdfs[hit.matId + 1u];
+      if (mix >= 1.f) rec = rec2;  // :273  the conductor alone
+      else blend = mix > 0.f;      // :272  metallic <= 0: the dielectric alone
+    }
+  }
+  if constexpr (TEX) {
+    if (TEX < 2 || kargs(k)->matTex != nullptr) {
+      ns = apply_material_textures(k, rec, hit.matId, bestTri, bu, bv, hit.normal);
+      if (blend) (void)apply_material_textures(k, rec2, hit.matId + 1u, bestTri, bu, bv, hit.normal);  // same roughness map
+    }
+  }
 #if DMT_SECTION_TIMING
   {  // material mix of the lanes that shade in this pass: [11] passes with a GGX lane, [12] GGX lanes, [13] passes, [14] lanes
     bool const ggx = hi16(rec.w[1]) != BS_OREN;
@@ -385,6 +419,27 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
   }
 #endif
   Bsdf const b = bsdf_prepare(rec, ns, wo);  // :165-166
+  Bsdf b2{};
+  if constexpr (TEX >= 2) {
+    if (blend) b2 = bsdf_prepare(rec2, ns, wo);
+  }
+  // f * weight and pdf of the material towards wi.  Blend: f = lerp(fD, fC, metallic), the RGB overload (a, b, t) of
+  // cudautils-color.cuh:112-114; pdf = lerp(pdfD, pdfC, metallic) resolves to the FLOAT overload dmt::lerp(float x, float a,
+  // float b) = (1 - x) a + x b (cudautils-vecmath.cuh:750-752), i.e. the reference computes (1 - pdfD) pdfC + pdfD metallic.
+  // Kept as written, on the sampling side too (core-material.cpp:282).
+  auto blend_pdf = [&](float pdfD, float pdfC) { return (1.f - pdfD) * pdfC + pdfD * mix; };
+  auto eval_material = [&](f3 wi, float& pdf) {
+    f3 f = eval_bsdf(b, wo, wi, ns, hit.normal, pdf) * b.weight;
+    if constexpr (TEX >= 2) {
+      if (blend) {
+        float pdfC = 0.f;
+        f3 const fC = eval_bsdf(b2, wo, wi, ns, hit.normal, pdfC) * b2.weight;
+        f = f * (1.f - mix) + fC * mix;
+        pdf = blend_pdf(pdf, pdfC);
+      }
+    }
+    return f;
+  };
   sect_mark(5);
 
   // next-event estimation (:170-241)
@@ -399,7 +454,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
       EnvSampleDev const es = env_sample(env, uLight2);
       if (es.ok) {
         float bsdfPdf = 0.f;
-        f3 const f = eval_bsdf(b, wo, es.wi, ns, hit.normal, bsdfPdf) * b.weight;
+        f3 const f = eval_material(es.wi, bsdfPdf);
         f3 const Le = env_eval_uv(env, es.uv);
         if (!is_zero(f) && max3(Le) > 0.f) {  // core-render.cpp:357-369: Le f / (pdfLight pmf + pdfBsdf), pmf = 1/2
           put_C(st.beta * (Le * f / (es.pdf * 0.5f + bsdfPdf)));
@@ -420,7 +475,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
       AreaSampleDev const as = area_sample(sc.post[ka->areaTri[ai]], hit.pos, uLight2);
       if (as.ok) {
         float bsdfPdf = 0.f;
-        f3 const f = eval_bsdf(b, wo, as.wi, ns, hit.normal, bsdfPdf) * b.weight;
+        f3 const f = eval_material(as.wi, bsdfPdf);
         if (!is_zero(f)) {
           f3 const Le = mk3(ka->areaLe[3 * ai], ka->areaLe[3 * ai + 1], ka->areaLe[3 * ai + 2]);
           float const a = as.pdf * (ENV ? 0.5f : 1.f) / float(nAll), bb = bsdfPdf;
@@ -451,7 +506,7 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
     sect_mark(6);
     if (picked && ls.valid()) {
       float bsdfPdf = 0.f;
-      f3 const f = eval_bsdf(b, wo, ls.direction, ns, hit.normal, bsdfPdf) * b.weight;
+      f3 const f = eval_material(ls.direction, bsdfPdf);
       if (!is_zero(f)) {
         f3 const Le = eval_light(light, ls);
         if (ls.delta) {
@@ -472,7 +527,16 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
   sect_mark(7);
   f2 const u2 = st.rng.get2D();
   float const uc = st.rng.get1D();
-  BsdfSample const bs = sample_bsdf(b, wo, ns, hit.normal, u2, uc);
+  BsdfSample bs = sample_bsdf(b, wo, ns, hit.normal, u2, uc);
+  if constexpr (TEX >= 2) {
+    if (blend) {  // core-material.cpp:275-286: both lobes sampled with the same numbers; direction and flags of the conductor's
+      BsdfSample sC = sample_bsdf(b2, wo, ns, hit.normal, u2, uc);
+      sC.f = bs.f * (1.f - mix) + sC.f * mix;
+      sC.pdf = blend_pdf(bs.pdf, sC.pdf);
+      sC.eta = 1.f;
+      bs = sC;
+    }
+  }
   sect_mark(8);
   if (!bs.valid()) return true;
   st.lastT = bs.refract;
@@ -575,11 +639,11 @@ DMT_DEV void trace_pair_bvh(KArgs k, PathState const& st, bool doC, bool doS, ui
 
 // One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
 // sink(L, sidx) is called once per completed sample with the index the sample was started with.
-template <bool ENV = false, bool AREA = false, bool TEX = false, bool LTREE = false, class Sink>
+template <bool ENV = false, bool AREA = false, int TEX = false, bool LTREE = false, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink);
 
-template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false, bool LTREE = false, class Sink>
+template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, int TEX = false, bool LTREE = false, class Sink>
 DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneStats* ls = nullptr) {
   bool const doC = st.active;
   bool const doS = st.hasShadow;
@@ -596,7 +660,7 @@ DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneS
 }
 
 // Second half of a ray pass: resolve the shadow ray (in the reference's accumulation order), then shade.
-template <bool ENV, bool AREA, bool TEX, bool LTREE, class Sink>
+template <bool ENV, bool AREA, int TEX, bool LTREE, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink) {
   if (doS) {
@@ -1086,7 +1150,7 @@ DMT_DEV void flush_stats(KArgs Pk, LaneStats const& ls) {
   }
 }
 
-template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false, bool LTREE = false>
+template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, int TEX = false, bool LTREE = false>
 DMT_DEV void megakernel_body() {
   KArgs const Pk = kargs_base();
   LaneStats ls;
@@ -1146,7 +1210,7 @@ DMT_DEV void megakernel_body() {
 #ifndef DMT_BVH_DUMMY_LDS
 #define DMT_BVH_DUMMY_LDS 0  // occupancy experiments: extra LDS bytes per block (fewer resident blocks per CU)
 #endif
-template <bool STATS = false, bool ENV = false, bool AREA = false, bool TEX = false, bool LTREE = false>
+template <bool STATS = false, bool ENV = false, bool AREA = false, int TEX = false, bool LTREE = false>
 DMT_DEV void megakernel_body_bvh() {
   KArgs const Pk = kargs_base();
 #if DMT_BVH_DUMMY_LDS > 0
@@ -1276,6 +1340,12 @@ __global__ void __launch_bounds__(256, 4) k_megakernel_tex(RenderParams P) { meg
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_tex(RenderParams P) { megakernel_body_bvh<false, false, false, true>(); }
 __global__ void __launch_bounds__(256, 4) k_megakernel_env_tex(RenderParams P) { megakernel_body<false, false, true, false, true>(); }
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_env_tex(RenderParams P) { megakernel_body_bvh<false, true, false, true>(); }
+// SURVEY 8f-1 fractional / textured "metallic": the texture kernels plus the two-lobe blend (a second prepared BSDF per lane:
+// one wave per SIMD fewer than the texture kernels, whose register allocation stays untouched)
+__global__ void __launch_bounds__(256, 3) k_megakernel_blend(RenderParams P) { megakernel_body<false, false, false, false, 2>(); }
+__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_blend(RenderParams P) { megakernel_body_bvh<false, false, false, 2>(); }
+__global__ void __launch_bounds__(256, 3) k_megakernel_env_blend(RenderParams P) { megakernel_body<false, false, true, false, 2>(); }
+__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_env_blend(RenderParams P) { megakernel_body_bvh<false, true, false, 2>(); }
 // light tree compiled in (dmt_set_light_sampling(DMT_LIGHTS_TREE) selects them); with or without the env map
 __global__ void __launch_bounds__(256, 4) k_megakernel_ltree(RenderParams P) { megakernel_body<false, false, false, false, false, true>(); }
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_ltree(RenderParams P) { megakernel_body_bvh<false, false, false, false, true>(); }
@@ -1571,6 +1641,7 @@ struct dmt_ctx {
   uint32_t* d_matTex = nullptr;
   float* d_triUv = nullptr;
   uint32_t texCount = 0, matTexCount = 0;
+  bool hasBlend = false;  // some uploaded BSDF record is a BS_GGX_BLEND pair: the *_tex kernels carry that code
   size_t triUvCount = 0;
   // wavefront form of the BVH path (wavefront.hpp)
   int bvhStrategy = 0;             // 0 = automatic (by launch size), 1 = megakernel, 2 = wavefront
@@ -1719,7 +1790,7 @@ SamplerParams computeSamplerParams(int width, int height) {
 
 // the light tree applies to plain point / spot light lists; textured or emissive-triangle scenes keep the uniform pick
 bool useLightTree(dmt_ctx const* c) {
-  return c->lightSampling == DMT_LIGHTS_TREE && c->lightCount > 1 && c->lightsTreeable && c->areaCount == 0 && c->texCount == 0;
+  return c->lightSampling == DMT_LIGHTS_TREE && c->lightCount > 1 && c->lightsTreeable && c->areaCount == 0 && c->texCount == 0 && !c->hasBlend;
 }
 int ensureLightTree(dmt_ctx* ctx);
 
@@ -1758,6 +1829,7 @@ RenderParams baseParams(dmt_ctx const* c, size_t threads) {
 typedef void (*MegakernelFn)(RenderParams);
 MegakernelFn megakernelOf(dmt_ctx const* c) {
   bool const bvh = c->accel == DMT_ACCEL_BVH, env = c->env.w > 0, area = c->areaCount > 0, tex = c->texCount > 0;
+  if (c->hasBlend) return bvh ? (env ? k_megakernel_bvh_env_blend : k_megakernel_bvh_blend) : (env ? k_megakernel_env_blend : k_megakernel_blend);
   if (tex) return bvh ? (env ? k_megakernel_bvh_env_tex : k_megakernel_bvh_tex) : (env ? k_megakernel_env_tex : k_megakernel_tex);
   if (useLightTree(c)) return bvh ? (env ? k_megakernel_bvh_env_ltree : k_megakernel_bvh_ltree) : (env ? k_megakernel_env_ltree : k_megakernel_ltree);
   if (area && env) return bvh ? k_megakernel_bvh_env_area : k_megakernel_env_area;
@@ -2059,6 +2131,19 @@ int dmt_upload_bsdfs(dmt_ctx* ctx, const void* bsdf32, uint32_t count) {
   int rc = devAlloc(ctx, &ctx->d_bsdfs, count);
   if (rc) return rc;
   if (count) HIP_TRY(ctx, hipMemcpy(ctx->d_bsdfs, bsdf32, size_t(count) * 32, hipMemcpyHostToDevice));
+  // fractional-metallic materials (BS_GGX_BLEND: this record + the conductor record after it) run on the *_tex kernels
+  ctx->hasBlend = false;
+  for (uint32_t i = 0; i < count; ++i) {
+    uint32_t w1;
+    memcpy(&w1, static_cast<unsigned char const*>(bsdf32) + 32 * size_t(i) + 4, 4);
+    if ((w1 >> 16) == BS_GGX_BLEND) {
+      uint32_t w1next = 0;
+      if (i + 1 < count) memcpy(&w1next, static_cast<unsigned char const*>(bsdf32) + 32 * size_t(i + 1) + 4, 4);
+      if (i + 1 >= count || (w1next >> 16) != BS_GGX_COND)
+        return fail(ctx, DMT_ERR_INVALID, "dmt_upload_bsdfs: a blend record (type 4) must be followed by its GGX conductor record");
+      ctx->hasBlend = true;
+    }
+  }
   ctx->bsdfCount = count;
   ctx->haveBsdfs = true;
   return DMT_OK;
@@ -2370,7 +2455,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   uint32_t const ownedTiles = P.numItems;
   // BVH launches run as the megakernel unless the wavefront form (wavefront.hpp) is asked for: on the measured scenes
   // the megakernel is faster (1 M triangles: 489 vs 378 Msamples/s), so "automatic" means megakernel
-  bool const wavefront = ctx->accel == DMT_ACCEL_BVH && ctx->bvhStrategy == 2 && ctx->texCount == 0 && !useLightTree(ctx);  // textures / light tree: megakernels only
+  bool const wavefront = ctx->accel == DMT_ACCEL_BVH && ctx->bvhStrategy == 2 && ctx->texCount == 0 && !ctx->hasBlend && !useLightTree(ctx);  // textures / blends / light tree: megakernels only
   {  // fewer owned tiles than ~4 per resident wave: schedule row bands of the tiles instead of whole tiles
     uint32_t const waves = uint32_t(ctx->cuCount) * uint32_t(blocksPerCuOf(ctx)) * 4u;
     P.subShift = ctx->subShift >= 0 ? uint32_t(ctx->subShift) : 0u;
@@ -2395,6 +2480,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   bool const useArea = ctx->areaCount > 0;
   P.env = ctx->env;
   P.areaOf = ctx->d_areaOf, P.areaTri = ctx->d_areaTri, P.areaLe = ctx->d_areaLe, P.areaCount = ctx->areaCount;
+  if (ctx->hasBlend && useArea) return fail(ctx, DMT_ERR_STATE, "dmt_render: fractional-metallic materials together with emissive triangles are not supported");
   if (ctx->texCount > 0) {
     if (useArea) return fail(ctx, DMT_ERR_STATE, "dmt_render: image textures together with emissive triangles are not supported");
     if (ctx->matTexCount != ctx->bsdfCount || ctx->triUvCount != ctx->triCount)

@@ -874,7 +874,11 @@ DMT_DEV f3 eval_light(Rec32 const& L, LightSample const& ls) {  // light.cu:309-
 // The reference mutates the packed record per hit (prepareBSDF) and re-reads it; here the
 // record is decoded once into registers and every fp16 store of the reference becomes q16().
 // ---------------------------------------------------------------------------------------------
-enum : uint32_t { BS_OREN = 0, BS_GGX_DIEL = 1, BS_GGX_COND = 2, BS_LAMBERT = 3 };
+enum : uint32_t { BS_OREN = 0, BS_GGX_DIEL = 1, BS_GGX_COND = 2, BS_LAMBERT = 3,
+                  // This build's own tag: a GGX dielectric record of a material that is "metallic" by a fraction; the NEXT record
+                  // of the array is its GGX conductor, the first half of the weight field holds the fraction (fp16).  Blended as
+                  // the reference's CPU renderer does (core-material.cpp:275-286, :383-394); *_tex kernels only (path_shade).
+                  BS_GGX_BLEND = 4 };
 
 __constant__ float c_ggxE[DMT_GGX_E_ROWS * DMT_GGX_E_COLS] = {DMT_GGX_E_TABLE_VALUES};
 __constant__ float c_ggxEavg[DMT_GGX_EAVG_COUNT] = {DMT_GGX_EAVG_TABLE_VALUES};

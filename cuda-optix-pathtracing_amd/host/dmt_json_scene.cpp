@@ -15,10 +15,10 @@
 //
 // What the reference feeds with this is its CPU renderer's scene graph.  Here the result is the megakernel's
 // flat scene, so three mappings are this build's own and are documented in DESIGN.md: materials become ONE packed
-// BSDF record each ("oren-nayar-dielectric" -> Oren-Nayar; else metallic < 0.5 -> GGX dielectric, >= 0.5 -> GGX
-// conductor, alpha_y = roughness, alpha_x = anisotropy * roughness as core-material.cpp:262-263), instances are
+// BSDF record each ("oren-nayar-dielectric" -> Oren-Nayar; else metallic <= 0 -> GGX dielectric, >= 1 -> GGX
+// conductor, in between both, core-material.cpp:272-286; alpha_y = roughness, alpha_x = anisotropy * roughness, :262-263), instances are
 // flattened (every vertex transformed on the host), and image textures (albedo of Oren-Nayar materials, roughness, normal maps) are sampled per hit by the *_tex kernels
-// (dmt_upload_textures); a textured 'metallic' is rejected: the material's BSDF kind is chosen once, on the host.  FBX objects go through this build's own binary reader (dmt_fbx.cpp).
+// (dmt_upload_textures); a fractional or textured 'metallic' makes a record PAIR blended per hit (packMaterial).  FBX objects go through this build's own binary reader (dmt_fbx.cpp).
 #include <zlib.h>
 
 #include <cmath>
@@ -118,7 +118,10 @@ struct Material {
   float anisotropy = 1.f;  // (the reference leaves 0 when "ggx-anisotropy" is absent, which makes alpha_x = 0)
   Vec3 reflectanceTint{1, 1, 1}, transmittanceTint{1, 1, 1};
   bool orenNayar = false;
-  int32_t diffuseTex = -1, roughnessTex = -1, normalTex = -1;  // indices into State::textureList
+  int32_t diffuseTex = -1, roughnessTex = -1, normalTex = -1, metallicTex = -1;  // indices into State::textureList
+  // 0 < metallic < 1, or a metallic map: the material becomes TWO records (dielectric tagged BS_GGX_BLEND, then conductor)
+  bool blend() const { return !orenNayar && (metallicTex >= 0 || (metallic > 0.f && metallic < 1.f)); }
+  int records() const { return blend() ? 2 : 1; }
 };
 struct LightProto {
   bool spot = false;
@@ -164,11 +167,22 @@ std::vector<Triangle> unitPlane() {
   return {Triangle{P[0], P[3], P[2]}, Triangle{P[0], P[1], P[3]}};
 }
 
-Packed32 packMaterial(Material const& m) {
-  if (m.orenNayar) return makeOrenNayar(m.diffuse, m.roughness);
+// core-material.cpp:272-286: metallic <= 0 -> the dielectric lobe alone, >= 1 -> the conductor alone, in between (or a
+// metallic map) both, blended per hit: the dielectric record tagged BS_GGX_BLEND followed by the conductor record
+void packMaterial(Material const& m, std::vector<Packed32>& out) {
+  if (m.orenNayar) {
+    out.push_back(makeOrenNayar(m.diffuse, m.roughness));
+    return;
+  }
   float const alphay = m.roughness, alphax = m.anisotropy * m.roughness;  // core-material.cpp:262-263
-  if (m.metallic >= 0.5f) return makeGGXConductor(m.eta, m.etak, 0.f, alphax, alphay);
-  return makeGGXDielectric(m.reflectanceTint, m.transmittanceTint, 0.f, m.ior, alphax, alphay);
+  if (m.blend()) {
+    out.push_back(makeGGXBlendDielectric(m.reflectanceTint, m.transmittanceTint, 0.f, m.ior, alphax, alphay, m.metallic));
+    out.push_back(makeGGXConductor(m.eta, m.etak, 0.f, alphax, alphay));
+  } else if (m.metallic >= 1.f) {
+    out.push_back(makeGGXConductor(m.eta, m.etak, 0.f, alphax, alphay));
+  } else {
+    out.push_back(makeGGXDielectric(m.reflectanceTint, m.transmittanceTint, 0.f, m.ior, alphax, alphay));
+  }
 }
 
 struct State {
@@ -179,6 +193,7 @@ struct State {
   std::map<std::string, LightProto> lights;
   std::map<std::string, Mat4> transforms;
   std::vector<Material> materialList;
+  uint32_t recordCount = 0;  // packed BSDF records so far (a blend material takes two)
   std::vector<Mesh> meshes;
   std::vector<Mat4> stack;
 };
@@ -249,8 +264,6 @@ float scalarOrTexture(Value const& v, char const* key, State const& st, int32_t*
     if (!st.textures.count(v.string)) fail(std::string("'") + key + "' texture name should be an existing named texture");
     Texture const& t = st.textureList[st.textures.at(v.string)];
     if (t.type != key) fail(std::string("'") + key + "' material texture should point to a '" + key + "' texture");
-    if (!tex) fail(std::string("material '") + key + "' refers to texture '" + v.string + "': a textured '" + key +
-                   "' is not supported on the megakernel path (one BSDF kind per material)");
     *tex = int32_t(st.textures.at(v.string));
     return 0.5f;
   }
@@ -288,7 +301,7 @@ void parseMaterial(Value const& m, State& st) {
     mat.normalTex = int32_t(st.textures.at(m.at("normal").string));
   }
   mat.roughness = scalarOrTexture(m.at("roughness"), "roughness", st, &mat.roughnessTex);
-  mat.metallic = scalarOrTexture(m.at("metallic"), "metallic", st, nullptr);
+  mat.metallic = scalarOrTexture(m.at("metallic"), "metallic", st, &mat.metallicTex);
   if (m.contains("ior")) {
     if (!m.at("ior").isNumber()) fail("material 'ior' should be a number");
     mat.ior = std::fmax(float(m.at("ior").number), 1.f);
@@ -335,7 +348,9 @@ void parseMaterial(Value const& m, State& st) {
     }
     mat.orenNayar = true;
   }
-  st.materials[name] = uint32_t(st.materialList.size());
+  if (mat.orenNayar && mat.metallicTex >= 0) fail("material '" + name + "': a 'metallic' texture on an 'oren-nayar-dielectric' material is not supported");
+  st.materials[name] = st.recordCount;  // index of the material's (first) packed record
+  st.recordCount += uint32_t(mat.records());
   st.materialList.push_back(mat);
 }
 
@@ -612,17 +627,20 @@ bool loadJsonScene(std::string const& path, JsonScene& out, std::string* error) 
       walkWorld(kv.second, st, out.scene);
       st.stack.pop_back();
     }
-    for (Material const& m : st.materialList) out.scene.bsdfs.push_back(packMaterial(m));
+    for (Material const& m : st.materialList) packMaterial(m, out.scene.bsdfs);
     // image textures: only when some material uses one (otherwise the plain kernels run and nothing is uploaded)
     bool textured = false;
-    for (Material const& m : st.materialList) textured = textured || m.diffuseTex >= 0 || m.roughnessTex >= 0 || m.normalTex >= 0;
+    for (Material const& m : st.materialList)
+      textured = textured || m.diffuseTex >= 0 || m.roughnessTex >= 0 || m.normalTex >= 0 || m.metallicTex >= 0;
     if (textured) {
       out.scene.texRgba = std::move(st.texels);
       for (Texture const& t : st.textureList) out.scene.texDesc.insert(out.scene.texDesc.end(), {t.first, t.width, t.height});
-      for (Material const& m : st.materialList) {
+      for (Material const& m : st.materialList) {  // one row per packed RECORD
         uint32_t bits;
         memcpy(&bits, &m.anisotropy, 4);
         out.scene.matTex.insert(out.scene.matTex.end(), {uint32_t(m.diffuseTex), uint32_t(m.roughnessTex), uint32_t(m.normalTex), bits});
+        // the conductor half of a blend: same roughness map and normal map; its first slot carries the METALLIC map
+        if (m.blend()) out.scene.matTex.insert(out.scene.matTex.end(), {uint32_t(m.metallicTex), uint32_t(m.roughnessTex), uint32_t(m.normalTex), bits});
       }
     } else {
       out.scene.triUv.clear();

@@ -165,6 +165,17 @@ Packed32 makeGGXDielectric(Vec3 reflectanceTint, Vec3 transmittanceTint, float p
   f.half3(bsdf_off::dTrans, transmittanceTint);
   return f.rec;
 }
+// This build's own record (pt_device.hpp BS_GGX_BLEND): the dielectric half of a material that is "metallic" by a
+// fraction; the conductor record of the same material follows it in the array.  The fraction sits in the first half of
+// the weight field, which prepareBSDF overwrites for GGX records anyway.
+Packed32 makeGGXBlendDielectric(Vec3 reflectanceTint, Vec3 transmittanceTint, float phi0, float eta, float alphax, float alphay,
+                                float metallic) {
+  Fields f;
+  f.rec = makeGGXDielectric(reflectanceTint, transmittanceTint, phi0, eta, alphax, alphay);
+  f.u16(bsdf_off::type, 4);
+  f.half(bsdf_off::weight, metallic);
+  return f.rec;
+}
 Packed32 makeGGXConductor(Vec3 eta, Vec3 kappa, float phi0, float alphax, float alphay) {
   Fields f = newBsdf(kGGXConductor, {1, 1, 1});
   ggxCommon(f, alphax, alphay, phi0);

@@ -40,6 +40,8 @@ Packed32 makeOrenNayar(Vec3 color, float roughness);
 Packed32 makeGGXDielectric(Vec3 reflectanceTint, Vec3 transmittanceTint, float phi0, float eta,
                            float alphax, float alphay);
 Packed32 makeGGXConductor(Vec3 eta, Vec3 kappa, float phi0, float alphax, float alphay);
+Packed32 makeGGXBlendDielectric(Vec3 reflectanceTint, Vec3 transmittanceTint, float phi0, float eta, float alphax, float alphay,
+                                float metallic);
 // light packers (CC/private/light.cu:271-307)
 Packed32 makePointLight(Vec3 color, Vec3 position, float radius);
 Packed32 makeSpotLight(Vec3 color, Vec3 position, Vec3 direction, float cosTheta0, float cosThetaE,

@@ -303,7 +303,12 @@ enum : int {
   GC_ETA = 18,    // 3 x fp16
   GC_K = 24,      // 3 x fp16
 };
-enum : uint16_t { BS_OREN = 0, BS_GGX_DIEL = 1, BS_GGX_COND = 2, BS_LAMBERT = 3 };
+enum : uint16_t { BS_OREN = 0, BS_GGX_DIEL = 1, BS_GGX_COND = 2, BS_LAMBERT = 3,
+                  // This build's own tag (the megakernel's packed format has no such record): a GGX dielectric record whose
+                  // material is "metallic" by a fraction.  The record that FOLLOWS it in the array is the material's GGX
+                  // conductor, and the first half of the (otherwise unused) weight field holds the metallic fraction as fp16.
+                  // Semantics: the reference CPU renderer's blend, core-material.cpp:275-286 (sample) and :383-394 (eval).
+                  BS_GGX_BLEND = 4 };
 // Light offsets
 enum : int {
   L_INT = 0,     // 3 x fp16
@@ -1823,6 +1828,22 @@ inline V3 textureBilinear(Scene const& sc, int32_t tex, float s, float t, bool i
 }
 // Applies the material's textures at a hit: patches the packed record the way the host packers build it
 // (makeOrenNayar / bsdfGGXCommon above) from the sampled albedo / roughness, and returns the shading normal.
+// metallic fraction of a BS_GGX_BLEND material at a hit: the record's constant, or the material's 1-channel metallic map
+// (core-material.cpp:209-216; its index sits in the FIRST texture slot of the pair's second row, which a conductor
+// record has no other use for)
+inline float blendMetallic(Scene const& sc, Rec32 const& rec, uint32_t matId, int tri, float bu, float bv) {
+  float m = h2f(rd16(rec, B_WEIGHT));
+  if (sc.matTex && sc.triUv) {
+    int32_t const texM = int32_t(sc.matTex[4 * (matId + 1)]);
+    if (texM >= 0) {
+      float const* uv = sc.triUv + 6 * size_t(tri);
+      float const w0 = 1.f - bu - bv;
+      float const s = w0 * uv[0] + bu * uv[2] + bv * uv[4], t = w0 * uv[1] + bu * uv[3] + bv * uv[5];
+      m = textureBilinear(sc, texM, s, t, false).x;
+    }
+  }
+  return m;
+}
 inline V3 applyMaterialTextures(Scene const& sc, Rec32& rec, uint32_t matId, int tri, float bu, float bv, V3 ng) {
   if (!sc.matTex || !sc.triUv) return ng;
   uint32_t const* m = sc.matTex + 4 * matId;
@@ -1939,8 +1960,40 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
     if (depth >= cfg.maxDepth) break;
     if (st) st->bounces++, st->hits++;
     bsdf = sc.bsdfs[hit.matId];
+    // fractional "metallic" (BS_GGX_BLEND): both lobes of the material are prepared, evaluated and sampled, and blended
+    // as the reference's CPU renderer does (core-material.cpp:275-286, :383-394)
+    Rec32 bsdf2{};
+    float mix = 0.f;
+    bool blend = false;
+    if (bsdfType(bsdf) == BS_GGX_BLEND) {
+      mix = blendMetallic(sc, bsdf, hit.matId, hitTri, hit.u, hit.v);
+      wr16(bsdf, B_TYPE, BS_GGX_DIEL);
+      bsdf2 = sc.bsdfs[hit.matId + 1];
+      if (mix >= 1.f) bsdf = bsdf2;                       // :273  metallic >= 1: the conductor alone
+      else blend = mix > 0.f;                             // :272  metallic <= 0: the dielectric alone
+    }
     V3 const ns = applyMaterialTextures(sc, bsdf, hit.matId, hitTri, hit.u, hit.v, hit.normal);  // = hit.normal without textures
     prepareBSDF(&bsdf, ns, -ray.d, transmissionCount);
+    if (blend) {
+      (void)applyMaterialTextures(sc, bsdf2, hit.matId + 1, hitTri, hit.u, hit.v, hit.normal);  // same roughness map, same normal
+      prepareBSDF(&bsdf2, ns, -ray.d, transmissionCount);
+    }
+    // f * weight and pdf of the material towards wi.  Blend: result.f = lerp(fD, fC, metallic) with the RGB overload
+    // (a, b, t) of cudautils-color.cuh:112-114; result.pdf = lerp(pdfD, pdfC, metallic) resolves to the FLOAT overload
+    // dmt::lerp(float x, float a, float b) = (1 - x) a + x b (cudautils-vecmath.cuh:750-752), whose first argument is the
+    // parameter: the reference computes (1 - pdfD) pdfC + pdfD metallic.  Kept as written (it decides pixels); the same
+    // expression serves the sampling side (core-material.cpp:282).
+    auto blendPdf = [&](float pdfD, float pdfC) { return (1.f - pdfD) * pdfC + pdfD * mix; };
+    auto evalMaterial = [&](V3 wo, V3 wi, float* pdf) {
+      V3 f = evalBsdf(bsdf, wo, wi, ns, hit.normal, pdf) * bsdfWeight(bsdf);
+      if (blend) {
+        float pdfC = 0;
+        V3 const fC = evalBsdf(bsdf2, wo, wi, ns, hit.normal, &pdfC) * bsdfWeight(bsdf2);
+        f = f * (1.f - mix) + fC * mix;
+        *pdf = blendPdf(*pdf, pdfC);
+      }
+      return f;
+    };
 
     float uLight = rng.get1D();
     V2 const uLight2 = rng.get2D();
@@ -1975,7 +2028,7 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
         }
         if (visible) {
           float bsdfPdf = 0;
-          V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, ns, hit.normal, &bsdfPdf) * bsdfWeight(bsdf);
+          V3 const f = evalMaterial(-ray.d, shadow.d, &bsdfPdf);
           if (!isZero(f)) {
             V3 const Le = v3(sc.areaLe[3 * areaIdx], sc.areaLe[3 * areaIdx + 1], sc.areaLe[3 * areaIdx + 2]);
             float const a = as.pdf * listPmfScale / float(sc.lightCount + sc.areaCount), b = bsdfPdf;
@@ -1998,7 +2051,7 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
         }
         if (visible) {
           float bsdfPdf = 0;
-          V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, ns, hit.normal, &bsdfPdf) * bsdfWeight(bsdf);
+          V3 const f = evalMaterial(-ray.d, shadow.d, &bsdfPdf);
           V3 const Le = envEvalUv(*sc.env, es.uv);
           // core-render.cpp:357-369: Le f / (pdfLight pmf + pdfBsdf), pmf = 1/2
           if (!isZero(f) && maxComponent(Le) > 0.f) L += beta * (Le * f / (es.pdf * 0.5f + bsdfPdf));
@@ -2031,8 +2084,7 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
         }
         if (doNEE) {
           float bsdfPdf = 0;
-          V3 const f = evalBsdf(bsdf, -ray.d, shadow.d, ns, hit.normal, &bsdfPdf) *
-                       bsdfWeight(bsdf);
+          V3 const f = evalMaterial(-ray.d, shadow.d, &bsdfPdf);
           V3 const Le = evalLight(light, ls);
           if (!isZero(f)) {
             if (ls.delta) {
@@ -2054,7 +2106,14 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
       u2 = rng.get2D();
       uc = rng.get1D();
     }
-    BSDFSample const bs = sampleBsdf(bsdf, -ray.d, ns, hit.normal, u2, uc);
+    BSDFSample bs = sampleBsdf(bsdf, -ray.d, ns, hit.normal, u2, uc);
+    if (blend) {  // core-material.cpp:275-286: both lobes sampled with the same numbers; direction and flags of the conductor's
+      BSDFSample sC = sampleBsdf(bsdf2, -ray.d, ns, hit.normal, u2, uc);
+      sC.f = bs.f * (1.f - mix) + sC.f * mix;
+      sC.pdf = blendPdf(bs.pdf, sC.pdf);
+      sC.eta = 1.f;
+      bs = sC;
+    }
     if (!bs.valid()) break;
     transmissionCount += bs.refract;
     lastBounceTransmission = bs.refract;

@@ -101,15 +101,19 @@ def load(path, O):
             t = F(_clamp(float(F(m["ggx-anisotropy"])), 0.0, 1.0))
             aniso = F(1) if t == 0 else F(F(F(8) - F(1)) * t) + F(1)
         ax, ay = F(aniso * rough), rough
-        if metal >= F(0.5):
-            eta = [max(float(F(v)), 0.0) for v in m.get("eta", [0.18299, 0.42108, 1.37340])]
-            etak = [max(float(F(v)), 0.0) for v in m.get("etak", [3.42420, 2.34590, 1.77040])]
+        eta = [max(float(F(v)), 0.0) for v in m.get("eta", [0.18299, 0.42108, 1.37340])]
+        etak = [max(float(F(v)), 0.0) for v in m.get("etak", [3.42420, 2.34590, 1.77040])]
+        g = m.get("ggx-dielectric") or {}
+        rt = [_clamp(float(F(v)), 0.0, 1.0) for v in g.get("reflectance-tint", [1, 1, 1])]
+        tt = [_clamp(float(F(v)), 0.0, 1.0) for v in g.get("transmittance-tint", [1, 1, 1])]
+        ior = max(float(F(m.get("ior", 1.4))), 1.0)
+        # core-material.cpp:272-286: <= 0 the dielectric, >= 1 the conductor, in between BOTH records (blended per hit)
+        if metal >= F(1):
+            bsdfs.append(O.make_ggx_conductor(eta, etak, 0.0, float(ax), float(ay)))
+        elif metal > F(0):
+            bsdfs.append(O.make_ggx_blend_dielectric(rt, tt, 0.0, ior, float(ax), float(ay), float(metal)))
             bsdfs.append(O.make_ggx_conductor(eta, etak, 0.0, float(ax), float(ay)))
         else:
-            g = m.get("ggx-dielectric") or {}
-            rt = [_clamp(float(F(v)), 0.0, 1.0) for v in g.get("reflectance-tint", [1, 1, 1])]
-            tt = [_clamp(float(F(v)), 0.0, 1.0) for v in g.get("transmittance-tint", [1, 1, 1])]
-            ior = max(float(F(m.get("ior", 1.4))), 1.0)
             bsdfs.append(O.make_ggx_dielectric(rt, tt, 0.0, ior, float(ax), float(ay)))
     objects = {}
     for o in data["objects"]:

@@ -364,6 +364,15 @@ def make_ggx_dielectric(rt, tt, phi0, eta, ax, ay):
                 C.c_float(ax), C.c_float(ay))
 
 
+def make_ggx_blend_dielectric(rt, tt, phi0, eta, ax, ay, metallic):
+    """The dielectric half of a fractional-metallic material (this build's BS_GGX_BLEND tag = 4, the fraction as fp16 in the
+    first half of the weight field); its conductor record follows it in the BSDF array."""
+    rec = make_ggx_dielectric(rt, tt, phi0, eta, ax, ay).copy()
+    rec[0:2] = np.array([lib().oracle_float_to_half(C.c_float(metallic))], np.uint16).view(np.uint8)
+    rec[6:8] = np.array([4], np.uint16).view(np.uint8)
+    return rec
+
+
 def make_ggx_conductor(eta, kappa, phi0, ax, ay):
     return _rec(lib().oracle_make_ggx_conductor, _f3(eta), _f3(kappa), C.c_float(phi0), C.c_float(ax),
                 C.c_float(ay))

@@ -38,6 +38,24 @@ def test_loader_matches_restatement(pkg, O):
     assert (got.max_depth, got.spp) == (6, 8)
 
 
+def test_fractional_metallic_becomes_a_record_pair(pkg, O, tmp_path):
+    """core-material.cpp:272-286: metallic <= 0 -> dielectric, >= 1 -> conductor, in between BOTH lobes (blended per hit):
+    the loader emits the dielectric record tagged BS_GGX_BLEND with the fraction in its weight field, followed by the
+    conductor record; later materials' indices shift; packed bytes equal the numpy restatement's."""
+    def edit(d):
+        d["materials"][1]["metallic"] = 0.3          # 'gold' of the fixture: was 1.0
+    p = _variant(tmp_path, edit)
+    got = pkg.host_scene.load_json(p)
+    ref = json_scene_ref.load(p, O)
+    assert got.bsdfs.shape[0] == 4 and np.array_equal(got.bsdfs, ref["bsdfs"])
+    types = [int(r[6:8].view(np.uint16)[0]) for r in got.bsdfs]
+    assert types == [1, 4, 2, 0]                     # glass, gold (blend dielectric + conductor), chalk
+    assert abs(float(got.bsdfs[1, 0:2].view(np.float16)[0]) - 0.3) < 2e-4
+    assert np.array_equal(got.mat_id, ref["mat_id"]) and got.mat_id.tolist() == [3] * 2 + [0] * 12 + [1] * 12
+    # the two GGX records of the pair share the material's alphas
+    assert np.array_equal(got.bsdfs[1, 12:18], got.bsdfs[2, 12:18])
+
+
 def test_envlight_png_is_loaded_as_bytes_over_255(pkg):
     got = pkg.host_scene.load_json(SCENE)
     assert got.env_rgb.shape == (16, 32, 3)
@@ -274,11 +292,16 @@ def test_texture_rules_of_the_parser(pkg, tmp_path):
         load(lambda j: j["materials"][0].__setitem__("roughness", "nope"))
     with pytest.raises(ValueError, match="expect 1 channel"):
         load(lambda j: j["textures"][2].__setitem__("path", "./res/textures/chippedPaint/Paint_Chipped_1K_albedo.png"))
-    with pytest.raises(ValueError, match="not supported on the megakernel path"):
-        def metallic_tex(j):
-            j["textures"].append({"name": "m", "type": "metallic", "path": "./res/textures/chippedPaint/Paint_Chipped_1K_roughness.png"})
-            j["materials"][0]["metallic"] = "m"
-        load(metallic_tex)
+    # a 'metallic' MAP (1-channel): the material becomes a record pair -- dielectric tagged BS_GGX_BLEND (4), then its
+    # conductor -- with one texture row per record; the metallic map sits in the first slot of the SECOND row
+    def metallic_tex(j):
+        j["textures"].append({"name": "m", "type": "metallic", "path": "./res/textures/chippedPaint/Paint_Chipped_1K_roughness.png"})
+        j["materials"][0]["metallic"] = "m"
+    sm = load(metallic_tex)
+    assert sm.bsdfs.shape[0] == 2 and sm.bsdfs[0, 6:8].view(np.uint16)[0] == 4 and sm.bsdfs[1, 6:8].view(np.uint16)[0] == 2
+    assert sm.mat_tex.shape == (2, 4)
+    assert sm.mat_tex[0, :3].tolist() == [0, 2, 1] and sm.mat_tex[1, :3].tolist() == [3, 2, 1]
+    assert set(sm.mat_id.tolist()) == {0}
     s = load(lambda j: j["materials"][0].pop("normal"))
     assert s.mat_tex[0, :3].tolist() == [0, 2, 0xFFFFFFFF]
 
