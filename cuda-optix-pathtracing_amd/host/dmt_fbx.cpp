@@ -9,14 +9,32 @@
 // File format (Kaydara binary, versions 7100-7400: 32-bit record offsets; 7500+: 64-bit): 27-byte header, then
 // nested node records {end offset, property count, property bytes, name, properties, children, 13/25-byte null
 // record}; array properties (f d l i b) may be zlib-deflated.
-// NOT reproduced: the SDK's axis-system conversion (ImportFBX asks for Z-up / parity-odd / LEFT-handed; Blender
-// writes Z-up right-handed files, and what the SDK does to the geometry in that case cannot be checked here),
-// pre/post rotations, pivots, geometric transforms, instancing, animation.  Parity unpinned: no FBX SDK, no
-// reference-side vectors; tested against files written by this repo's own writer (tools/make_fbx_fixture.py)
-// and against the structure of the reference's scenes/sphere.fbx where that file is present.
+//
+// Axis system (core-mesh-parser.cpp:630-655).  ImportFBX converts the scene to FbxAxisSystem(eZAxis, eParityOdd,
+// eLeftHanded) before it bakes the node's global transform into the vertices.  In that system the UP vector is +Z, the
+// FRONT vector (FBX: the axis that points towards the viewer) is the second of the two remaining axes, +Y, and the third
+// ("coord") axis is X; a right-handed system has coord = up x front (Maya: Y x Z = +X; 3ds Max: Z x -Y = +X), so the
+// left-handed target has coord = -(Z x Y) = +X.  A file states its own system in GlobalSettings: UpAxis / UpAxisSign,
+// FrontAxis / FrontAxisSign, CoordAxis / CoordAxisSign (axis indices 0..2 and signs), i.e. three signed unit vectors
+// r (coord), u (up), f (front) in file coordinates.  The change of basis that carries each of them onto the target's
+// is  p' = ((p . r), (p . f), (p . u)):  a point keeps its "right / up / front" amounts.  When the file is right-handed
+// (det[r u f] = +1) that map is a reflection, so the triangles' winding is reversed with it (v1 <-> v2, UVs alike) to
+// keep outward faces outward; Blender's exports (Z up, -Y front, X coord: scenes/sphere.fbx, scenes/teapot.fbx) become
+// (x, -y, z).  DECISION, unpinned: whether the SDK's ConvertScene really mirrors geometry on a handedness change (it is
+// documented to edit node transforms only) cannot be checked without the SDK; this reader does what the requested target
+// system MEANS.  A file without these properties is taken as already in the target system (this repo's older fixtures).
+// One observation that speaks against it and is recorded rather than acted on: scenes/scene_test.json turns teapot.fbx
+// (Y up, +Z front, right-handed) by 180 degrees about x and puts it at z = -1.32 under a camera that looks slightly down;
+// with this reading the teapot stands along +z after the import, so the scene shows it upside down in the lower half of
+// the frame (profiles/r03/teapot_scene_test_*.png), whereas an import that left its height along -z would frame it upright
+// and centred.  No definition of the requested axis system yields that map, so it is not guessed at.
+// NOT reproduced: pre/post rotations, pivots, geometric transforms, parent chains, instancing, animation.  Parity
+// unpinned: no FBX SDK, no reference-side vectors; tested against files written by this repo's own writer
+// (tools/make_fbx_fixture.py, three axis systems) and against the structure of the reference's scenes/sphere.fbx.
 #include <zlib.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <fstream>
@@ -229,12 +247,33 @@ static bool readFbxMeshImpl(std::string const& path, std::vector<Triangle>& out,
   double const M[3][3] = {{cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx},
                           {sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx},
                           {-sy, cy * sx, cy * cx}};
+  // axis system of the file -> (Z up, +Y front, +X coord, left-handed): rows of A are the file's coord, front and up vectors
+  double A[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  bool mirrored = false;
+  if (Node const* gs = root.child("GlobalSettings")) {
+    double up = -1, upS = 1, fr = -1, frS = 1, co = -1, coS = 1;
+    bool const have = prop70(*gs, "UpAxis", &up, 1) && prop70(*gs, "FrontAxis", &fr, 1) && prop70(*gs, "CoordAxis", &co, 1);
+    prop70(*gs, "UpAxisSign", &upS, 1), prop70(*gs, "FrontAxisSign", &frS, 1), prop70(*gs, "CoordAxisSign", &coS, 1);
+    char const* const off = std::getenv("DMT_FBX_AXIS");  // diagnostic knob: DMT_FBX_AXIS=off reads the file's coordinates as they are
+    if (have && !(off && std::string(off) == "off")) {
+      int const iu = int(up), ifr = int(fr), ic = int(co);
+      if (iu < 0 || iu > 2 || ifr < 0 || ifr > 2 || ic < 0 || ic > 2 || iu == ifr || iu == ic || ifr == ic)
+        return bad("GlobalSettings: UpAxis / FrontAxis / CoordAxis are not a permutation of the three axes");
+      for (auto& row : A) row[0] = row[1] = row[2] = 0;
+      A[0][ic] = coS < 0 ? -1 : 1, A[1][ifr] = frS < 0 ? -1 : 1, A[2][iu] = upS < 0 ? -1 : 1;
+      double const det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                         A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+      mirrored = det < 0;  // rows (coord, front, up): det = -det[coord up front], negative for a right-handed file
+    }
+  }
   size_t const nv = V.size() / 3;
   std::vector<Vec3> P(nv);
   for (size_t i = 0; i < nv; ++i) {
     double const x = V[3 * i] * S[0], y = V[3 * i + 1] * S[1], z = V[3 * i + 2] * S[2];
-    P[i] = Vec3{float((M[0][0] * x + M[0][1] * y + M[0][2] * z + T[0]) * unit), float((M[1][0] * x + M[1][1] * y + M[1][2] * z + T[1]) * unit),
-                float((M[2][0] * x + M[2][1] * y + M[2][2] * z + T[2]) * unit)};
+    double const g[3] = {(M[0][0] * x + M[0][1] * y + M[0][2] * z + T[0]) * unit, (M[1][0] * x + M[1][1] * y + M[1][2] * z + T[1]) * unit,
+                         (M[2][0] * x + M[2][1] * y + M[2][2] * z + T[2]) * unit};  // the node's global transform, centimetres
+    P[i] = Vec3{float(A[0][0] * g[0] + A[0][1] * g[1] + A[0][2] * g[2]), float(A[1][0] * g[0] + A[1][1] * g[1] + A[1][2] * g[2]),
+                float(A[2][0] * g[0] + A[2][1] * g[1] + A[2][2] * g[2])};
   }
   // first LayerElementUV (what processUVLayerElement of core-mesh-parser.cpp reads): per polygon vertex ("ByPolygonVertex"),
   // direct or through UVIndex; other mappings (by control point) are resolved through the vertex index
@@ -271,10 +310,11 @@ static bool readFbxMeshImpl(std::string const& path, std::vector<Triangle>& out,
     polyCorner.push_back(corner++);
     if (last) {
       for (size_t k = 1; k + 1 < poly.size(); ++k) {
-        out.push_back(Triangle{P[poly[0]], P[poly[k]], P[poly[k + 1]]});
+        size_t const b = mirrored ? k + 1 : k, c = mirrored ? k : k + 1;  // a reflection reverses the winding
+        out.push_back(Triangle{P[poly[0]], P[poly[b]], P[poly[c]]});
         if (uv6) {
           float uv[6];
-          cornerUv(polyCorner[0], poly[0], uv), cornerUv(polyCorner[k], poly[k], uv + 2), cornerUv(polyCorner[k + 1], poly[k + 1], uv + 4);
+          cornerUv(polyCorner[0], poly[0], uv), cornerUv(polyCorner[b], poly[b], uv + 2), cornerUv(polyCorner[c], poly[c], uv + 4);
           uv6->insert(uv6->end(), uv, uv + 6);
         }
       }

@@ -17,9 +17,10 @@ literally the camera sits INSIDE the sphere (the importer carries a "TODO check 
 Both readings are tested: `fbx_example_literal.json` (the reference's file with only the env-map name changed from the
 non-existent .exr to the .png that ships beside it) and `c3_sphere_veranda.json` (the same scene with the object's
 transform scaled by 0.01, the metres reading: the sphere is seen from outside under the veranda map, which is the
-"NEE + MIS path" BASELINE config 3 names).  The SDK's axis conversion is not reproduced: for a mesh whose node has no
-rotation or translation it is an orthogonal map about the mesh origin, and what the SDK does on a handedness change
-cannot be checked without the SDK.  Parity of this config is oracle <-> HIP on identical arrays (unpinned by the
+"NEE + MIS path" BASELINE config 3 names).  The importer's axis-system conversion (to Z up / +Y front / left-handed,
+core-mesh-parser.cpp:636-655) is applied by this build's reader as a change of basis on the node's global transform
+(host/dmt_fbx.cpp, round 3): for sphere.fbx that is (x, y, z) -> (x, -y, z) with reversed winding, an orthogonal map about
+the mesh origin, invisible on the sphere.  Parity of this config is oracle <-> HIP on identical arrays (unpinned by the
 reference: its CPU renderer cannot be built here and ships no image of this scene).
 """
 import numpy as np
@@ -180,7 +181,9 @@ def test_reference_scene_test_json_textured_teapot(renderer, pkg, O):
         renderer.upload_textures(None, None, None, None)
     assert np.isfinite(mean).all() and np.all(m2[..., 3] == hs.spp)
     scale = float(mean[..., :3].mean())
-    assert film_rmse(mean, plain) > 2e-3 * scale                  # roughness texture + normal map change the teapot
+    # roughness texture + normal map change the teapot (seen from below since the importer's axis conversion stands it along
+    # z and the scene turns it over: 1.8e-3 of the mean; 7e-3 in the unconverted reading of round 2)
+    assert film_rmse(mean, plain) > 1e-3 * scale
     for y0, y1 in _band_rows(h, 4, 3):
         om, om2 = O.render(osc, hs.spp, max_depth=hs.max_depth, region=(0, y0, w, y1), threads=16)[:2]
         assert np.array_equal(m2[y0:y1, :, 3], om2[y0:y1, :, 3])

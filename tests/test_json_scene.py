@@ -151,6 +151,58 @@ def test_fbx_reader_fixture(pkg, tmp_path):
     assert (tmp_path / "again.fbx").read_bytes() == (GOLDEN / "fbx" / "uv_sphere_trs.fbx").read_bytes()
 
 
+@pytest.mark.parametrize("name", sorted(fbxfix.AXIS_FIXTURES))
+def test_fbx_axis_system_conversion(pkg, tmp_path, name):
+    """core-mesh-parser.cpp:630-655: the importer converts every file to (Z up, parity-odd = +Y front, left-handed) before
+    baking the node's transform.  Files declaring four different systems: the reader's triangles equal the numpy
+    restatement's (change of basis on the global transform, winding reversed when the map is a reflection), the committed
+    fixtures are reproducible, and an outward-wound sphere stays outward-wound in every system.  Unpinned (no SDK)."""
+    axes = fbxfix.AXIS_FIXTURES[name]
+    v, polys = fbxfix.uv_sphere()
+    got = pkg.host_scene.read_fbx(GOLDEN / "fbx" / f"uv_sphere_{name}.fbx")
+    want = fbxfix.expected_triangles(v, polys, axes=axes, **fbxfix.FIXTURE)
+    assert got.shape == want.shape and np.abs(got - want).max() < 1e-5
+    fbxfix.write(tmp_path / "again.fbx", v, polys, axes=axes, **fbxfix.FIXTURE)
+    assert (tmp_path / "again.fbx").read_bytes() == (GOLDEN / "fbx" / f"uv_sphere_{name}.fbx").read_bytes()
+    # same sphere without a node transform: geometric normals point away from the centre in the converted mesh
+    fbxfix.write(tmp_path / "plain.fbx", v, polys, axes=axes)
+    t = pkg.host_scene.read_fbx(tmp_path / "plain.fbx")
+    n = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])
+    assert (np.einsum("ij,ij->i", n, t.mean(axis=1)) > 0).all()
+    A = fbxfix.axis_matrix(axes)
+    mirrored = np.linalg.det(A) < 0
+    assert mirrored == (name.endswith("_rh"))             # right-handed files are reflected into the left-handed target
+    # the semantic directions land where the target puts them: file "up" -> +Z, "front" -> +Y, "coord" -> +X
+    e = np.eye(3)
+    assert np.allclose(A @ (e[axes["up"][0]] * axes["up"][1]), [0, 0, 1]) and np.allclose(A @ (e[axes["front"][0]] * axes["front"][1]), [0, 1, 0])
+    assert np.allclose(A @ (e[axes["coord"][0]] * axes["coord"][1]), [1, 0, 0])
+
+
+def test_fbx_axis_system_must_be_a_permutation(pkg, tmp_path):
+    v, polys = fbxfix.uv_sphere()
+    fbxfix.write(tmp_path / "bad.fbx", v, polys, axes=dict(up=(2, 1), front=(2, -1), coord=(0, 1)))
+    with pytest.raises(ValueError, match="not a permutation"):
+        pkg.host_scene.read_fbx(tmp_path / "bad.fbx")
+
+
+def test_reference_fbx_assets_axis_conversion(pkg, monkeypatch):
+    """The reference's own meshes (data fixtures).  scenes/sphere.fbx declares Blender's system (Z up, -Y front, X coord,
+    right-handed): (x, y, z) -> (x, -y, z).  scenes/teapot.fbx declares Y up, +Z front, X coord (right-handed): its height
+    runs along +Y in the file and along +Z -- the renderer's up -- after the conversion, (x, y, z) -> (x, z, y); read raw
+    (DMT_FBX_AXIS=off) it lies on its side.  Both maps are reflections, so v1 <-> v2."""
+    cases = ((GOLDEN / "c3" / "sphere.fbx", lambda r: r * np.array([1, -1, 1], np.float32)),
+             (GOLDEN / "scene_test" / "res" / "fbx" / "teapot.fbx", lambda r: r[..., [0, 2, 1]]))
+    for f, conv_of in cases:
+        conv = pkg.host_scene.read_fbx(f)
+        monkeypatch.setenv("DMT_FBX_AXIS", "off")
+        raw = pkg.host_scene.read_fbx(f)
+        monkeypatch.delenv("DMT_FBX_AXIS")
+        assert conv.shape == raw.shape
+        assert np.allclose(conv[:, [0, 2, 1]], conv_of(raw), atol=1e-6)
+    lo, hi = conv.reshape(-1, 3).min(0), conv.reshape(-1, 3).max(0)       # the teapot: stands on z = 0, 1.55 tall, spout along +x
+    assert abs(lo[2]) < 1e-6 and abs(hi[2] - 1.5497) < 1e-3 and hi[0] > 1.6 and abs(hi[1] + lo[1]) < 1e-5
+
+
 def test_fbx_reader_rejects_garbage(pkg, tmp_path):
     (tmp_path / "a.fbx").write_bytes(b"; FBX 7.4.0 project file\n")
     with pytest.raises(ValueError, match="not a binary FBX"):
