@@ -13,6 +13,7 @@ from .binding import (  # noqa: F401
     Renderer,
     bvh_validate,
     light_tree_pmfs,
+    light_tree_ref_select,
     envmap_tables,
     build_library,
     library_path,

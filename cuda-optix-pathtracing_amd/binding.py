@@ -51,7 +51,7 @@ def load_library():
 # every symbol include/dmt_hip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTED_SYMBOLS = [
     "dmt_ctx_create", "dmt_ctx_destroy", "dmt_last_error", "dmt_upload_triangles", "dmt_upload_bsdfs",
-    "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_light_sampling", "dmt_light_tree_pmfs", "dmt_set_bvh_strategy", "dmt_set_partition", "dmt_set_chunk", "dmt_render_profile",
+    "dmt_upload_lights", "dmt_set_camera", "dmt_set_limits", "dmt_set_accel", "dmt_set_light_sampling", "dmt_light_tree_pmfs", "dmt_light_tree_ref_select", "dmt_set_bvh_strategy", "dmt_set_partition", "dmt_set_chunk", "dmt_render_profile",
     "dmt_upload_area_lights", "dmt_upload_textures", "dmt_upload_envmap", "dmt_clear_envmap", "dmt_envmap_tables", "dmt_test_envmap",
     "dmt_set_stream", "dmt_film_clear", "dmt_film_bind", "dmt_film_device_ptrs", "dmt_download_film",
     "dmt_render", "dmt_render_stats", "dmt_sync", "dmt_sched_diag", "dmt_kernel_time", "dmt_kernel_info", "dmt_bvh_validate", "dmt_test_triangle_intersect",
@@ -83,6 +83,23 @@ def light_tree_pmfs(lights32, p, n):
     if rc != 0:
         raise DmtError(f"dmt_light_tree_pmfs failed ({rc})")
     return out, nc.value, d.value
+
+
+def light_tree_ref_select(lights32, p, n, u, start_pmf=1.0):
+    """Host-only: DMT_LIGHTS_TREE_REFERENCE's cut + selection (csrc/light_tree_ref.hpp ltr_select) at shading points p [k,3]
+    with normals n [k,3] and one random number each -> (indices [k,4] (-1 = none), pmfs [k,4], counts [k], node_count, depth)."""
+    lib = load_library()
+    L = np.ascontiguousarray(lights32, np.uint8).reshape(-1, 32)
+    p, n = _f32(p).reshape(-1, 3), _f32(n).reshape(-1, 3)
+    u = _f32(u).reshape(-1)
+    k = p.shape[0]
+    idx, pmf, cnt = np.zeros((k, 4), np.int32), np.zeros((k, 4), np.float32), np.zeros(k, np.int32)
+    nc, d = C.c_int(), C.c_int()
+    rc = lib.dmt_light_tree_ref_select(_p(L), C.c_uint32(L.shape[0]), C.c_int(k), _p(p), _p(n), _p(u), C.c_float(start_pmf), _p(idx), _p(pmf),
+                                       _p(cnt), C.byref(nc), C.byref(d))
+    if rc != 0:
+        raise DmtError(f"dmt_light_tree_ref_select failed ({rc})")
+    return idx, pmf, cnt, nc.value, d.value
 
 
 def bvh_validate(xs, ys, zs):

@@ -26,28 +26,30 @@ struct BvhView {
 
 __shared__ uint32_t s_bvh_stack[kBvhLdsStack * kLdsThreads];
 
+// The stack pointer is all a lane keeps.  The overflow column (entries beyond the LDS part, rare) is addressed from the
+// launch's view when it is needed: a lane's column is overflow + its global thread index, stride = threads of the launch.
+// (Round 2 kept the column pointer and the stride in three VGPRs of every lane for the whole kernel.)
 struct BvhStack {
   int sp;
-  uint32_t* ovf;  // this lane's overflow column
-  uint32_t stride;
   uint32_t* ovfCount = nullptr;  // stats build only: counts the pushes that went to the global overflow area
-  DMT_DEV void push(uint32_t ref) {
+  DMT_DEV static uint32_t* column(BvhView const& bv) { return bv.overflow + (blockIdx.x * blockDim.x + threadIdx.x); }
+  DMT_DEV void push(BvhView const& bv, uint32_t ref) {
     if (sp < kBvhLdsStack) {
       s_bvh_stack[sp * kLdsThreads + int(threadIdx.x)] = ref;
     } else {
-      ovf[size_t(sp - kBvhLdsStack) * stride] = ref;
+      column(bv)[size_t(sp - kBvhLdsStack) * bv.overflowStride] = ref;
       if (ovfCount) ++*ovfCount;
     }
     ++sp;
   }
-  DMT_DEV uint32_t pop() {
+  DMT_DEV uint32_t pop(BvhView const& bv) {
     if (sp == 0) return kBvhEmpty;
     --sp;
     // LDS read unconditional (clamped slot), global read only when needed: selecting between the two
     // POINTERS would make hipcc emit one flat_load through a generic pointer
     int const slot = sp < kBvhLdsStack ? sp : kBvhLdsStack - 1;
     uint32_t v = s_bvh_stack[slot * kLdsThreads + int(threadIdx.x)];
-    if (sp >= kBvhLdsStack) v = ovf[size_t(sp - kBvhLdsStack) * stride];
+    if (sp >= kBvhLdsStack) v = column(bv)[size_t(sp - kBvhLdsStack) * bv.overflowStride];
     return v;
   }
 };
@@ -215,10 +217,10 @@ DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc =
     tv.cur = p0 ? r0 : (top > 0 ? popped : kBvhEmpty);
     tv.stack.sp = p0 ? top : (top > 0 ? top - 1 : 0);
   } else {
-    if (p3) tv.stack.push(r3);
-    if (p2) tv.stack.push(r2);
-    if (p1) tv.stack.push(r1);
-    tv.cur = p0 ? r0 : tv.stack.pop();
+    if (p3) tv.stack.push(bv, r3);
+    if (p2) tv.stack.push(bv, r2);
+    if (p1) tv.stack.push(bv, r1);
+    tv.cur = p0 ? r0 : tv.stack.pop(bv);
   }
 }
 // leaf test: `ref` is a leaf reference (one triangle pair); updates the best hit / the occlusion flag only
@@ -239,7 +241,7 @@ DMT_DEV void trav_leaf_ref(BvhView const& bv, Traversal& tv, uint32_t ref, Trave
 template <bool STATS = false>
 DMT_DEV void trav_leaf(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
   trav_leaf_ref<STATS>(bv, tv, tv.cur, tc);
-  tv.cur = (tv.phase != TR_CLOSEST && tv.occluded) ? kBvhEmpty : tv.stack.pop();
+  tv.cur = (tv.phase != TR_CLOSEST && tv.occluded) ? kBvhEmpty : tv.stack.pop(bv);
 }
 // ---- whole traversals of one ray per lane (test kernels, lane_step<BVH>): the same step functions in a loop ----
 template <bool STATS>
@@ -257,7 +259,6 @@ template <bool STATS = false>
 DMT_DEV void bvh_closest(BvhView const& bv, bool active, f3 o, f3 d, uint32_t gtid, int& bestTri, float& bt,
                          float& bu, float& bvv, TraversalCounters* tc = nullptr) {
   Traversal tv{};
-  tv.stack.ovf = bv.overflow + gtid, tv.stack.stride = bv.overflowStride;
   if constexpr (STATS) tv.stack.ovfCount = &tc->overflowPushes;
   tv.phase = TR_CLOSEST;
   tv.bt = kInf, tv.bestTri = -1, tv.bestOrig = 0xFFFFFFFFu, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false, tv.tmax = kInf;
@@ -271,7 +272,6 @@ template <bool STATS = false>
 DMT_DEV bool bvh_any(BvhView const& bv, bool active, f3 o, f3 d, float tmax, uint32_t gtid,
                      TraversalCounters* tc = nullptr) {
   Traversal tv{};
-  tv.stack.ovf = bv.overflow + gtid, tv.stack.stride = bv.overflowStride;
   if constexpr (STATS) tv.stack.ovfCount = &tc->overflowPushes;
   tv.phase = TR_SHADOW;
   tv.bt = kInf, tv.bestTri = -1, tv.bestOrig = 0xFFFFFFFFu, tv.occluded = false, tv.tmax = tmax;

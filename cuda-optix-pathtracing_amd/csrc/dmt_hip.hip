@@ -31,6 +31,7 @@
 #include "bvh_device.hpp"
 #include "envmap.hpp"
 #include "light_tree.hpp"
+#include "light_tree_ref.hpp"
 
 using namespace dmt;
 
@@ -70,6 +71,7 @@ struct RenderParams {
   uint32_t const* matTex;     // [bsdf] {diffuse, roughness, normal texture or 0xFFFFFFFF, anisotropy as float bits}
   float const* triUv;         // [triangle] {u0, v0, u1, v1, u2, v2}
   LightTreeNode const* lightTree;  // light BVH over `lights` (light_tree.hpp); read by the *_ltree kernels only
+  LightTreeRefNode const* lightTreeRef;  // the reference-semantics tree (light_tree_ref.hpp); read by the *_ltree2 kernels only
   unsigned long long* stats;  // stats build only: samples, closest rays, shadow rays, node visits, triangle tests, bounces
 };
 
@@ -335,7 +337,9 @@ DMT_DEV f3 apply_material_textures(KArgs k, Rec32& rec, uint32_t matId, int tri,
   return (l2 > 0.f && l2 < kInf) ? ns / sqrtf(l2) : ng;
 }
 
-template <bool ENV = false, bool AREA = false, int TEX = false, bool LTREE = false>
+DMT_DEV void trace_pair_brute(KArgs k, PathState const& st, bool doC, bool doS, int& bestTri, float& bu, float& bv, bool& occluded);
+
+template <bool ENV = false, bool AREA = false, int TEX = false, int LTREE = false, bool BVH = false>
 DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv) {
   SceneView const sc = load_scene(k);
   int const maxDepth = kargs(k)->maxDepth;
@@ -487,11 +491,66 @@ DMT_DEV bool path_shade(KArgs k, PathState& st, int bestTri, float bu, float bv)
       }
     }
   }
-  if (!envNee && !areaNee && sc.lightCount > 0) {
+  bool treeNee = false;
+  if constexpr (LTREE == 2) {
+    // The reference's light tree with its own semantics (light_tree_ref.hpp): a cut of up to FOUR tree nodes, one light drawn
+    // below each, one shadow ray per light (core-render.cpp:296-370).  This loop carries one pending shadow ray per lane, so
+    // all but the LAST contributing light are tested for visibility right here (a whole any-hit traversal per ray; the
+    // lane's traversal stack is free while it shades) and added in the reference's order; the last one rides with the next
+    // closest-hit ray as usual.  Opt-in mode: the divergence of these in-line traversals is its price.
+    treeNee = !envNee && sc.lightCount > 1;
+    if (treeNee) {
+      LightTreeRefSelection const sel = ltr_select(kargs(k)->lightTreeRef, hit.pos.x, hit.pos.y, hit.pos.z, hit.normal.x, hit.normal.y,
+                                                   hit.normal.z, uLight, ENV ? 0.5f : 1.f);
+      bool pending = false;
+      f3 pendC = mk3(0, 0, 0), pendO = mk3(0, 0, 0), pendD = mk3(0, 0, 0);
+      float pendMax = 0.f;
+      for (uint32_t i = 0; i < sel.count; ++i) {
+        Rec32 const light = sc.lights[sel.indices[i]];
+        float const pmf = sel.pmfs[i];
+        LightSample const ls = sample_light(light, hit.pos, uLight2, st.lastT, hit.normal);
+        if (!ls.valid()) continue;
+        float bsdfPdf = 0.f;
+        f3 const f = eval_material(ls.direction, bsdfPdf);
+        if (is_zero(f)) continue;
+        f3 const Le = eval_light(light, ls);
+        f3 C;
+        if (ls.delta) {
+          C = st.beta * Le * f / pmf;
+        } else {
+          float const w = sqr(pmf * ls.pdf) / sqr(pmf * ls.pdf + bsdfPdf);
+          C = Le * f * st.beta * w;
+        }
+        if (pending) {  // an earlier light is waiting: resolve it now, keep this one pending
+          bool occ;
+          if constexpr (BVH) {
+            occ = bvh_any(load_bvh(k), true, pendO, pendD, pendMax, blockIdx.x * blockDim.x + threadIdx.x);
+          } else {
+            PathState tmp = st;
+            set_shadow_ray(tmp, pendO, pendD);
+            tmp.smax = pendMax;
+            int bt;
+            float tu, tvv;
+            trace_pair_brute(k, tmp, false, true, bt, tu, tvv, occ);
+          }
+          if (!occ) st.L = st.L + pendC;
+        }
+        pending = true, pendC = C, pendMax = ls.distance;
+        pendO = offset_ray_origin(hit.pos, hit.error, hit.normal, ls.direction), pendD = ls.direction;
+      }
+      if (pending) {
+        put_C(pendC);
+        set_shadow_ray(st, pendO, pendD);
+        st.smax = pendMax;
+        st.hasShadow = true;
+      }
+    }
+  }
+  if (!envNee && !areaNee && !treeNee && sc.lightCount > 0) {
     uint32_t li = 0;
     float pmf = 0.f;
     bool picked = true;
-    if constexpr (LTREE) {  // importance-driven choice (light_tree.hpp) instead of the uniform pick
+    if constexpr (LTREE == 1) {  // importance-driven choice (light_tree.hpp) instead of the uniform pick
       float treePmf = 0.f;
       int const sel = lt_select(kargs(k)->lightTree, hit.pos.x, hit.pos.y, hit.pos.z, hit.normal.x, hit.normal.y, hit.normal.z, uLight, treePmf);
       picked = sel >= 0;
@@ -639,11 +698,11 @@ DMT_DEV void trace_pair_bvh(KArgs k, PathState const& st, bool doC, bool doS, ui
 
 // One "ray pass" of a lane: trace (closest + pending shadow), resolve the shadow ray, shade.
 // sink(L, sidx) is called once per completed sample with the index the sample was started with.
-template <bool ENV = false, bool AREA = false, int TEX = false, bool LTREE = false, class Sink>
+template <bool ENV = false, bool AREA = false, int TEX = false, int LTREE = false, bool BVH = false, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink);
 
-template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, int TEX = false, bool LTREE = false, class Sink>
+template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, int TEX = false, int LTREE = false, class Sink>
 DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneStats* ls = nullptr) {
   bool const doC = st.active;
   bool const doS = st.hasShadow;
@@ -656,11 +715,11 @@ DMT_DEV void lane_step(KArgs k, uint32_t gtid, PathState& st, Sink&& sink, LaneS
     trace_pair_brute(k, st, doC, doS, bestTri, bu, bv, occluded);
   sect_mark(2);
   if constexpr (STATS) ls->bounces += (doC && bestTri >= 0 && st.depth < kargs(k)->maxDepth) ? 1u : 0u;
-  lane_finish<ENV, AREA, TEX, LTREE>(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
+  lane_finish<ENV, AREA, TEX, LTREE, BVH>(k, st, doC, doS, bestTri, bu, bv, occluded, sink);
 }
 
 // Second half of a ray pass: resolve the shadow ray (in the reference's accumulation order), then shade.
-template <bool ENV, bool AREA, int TEX, bool LTREE, class Sink>
+template <bool ENV, bool AREA, int TEX, int LTREE, bool BVH, class Sink>
 DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri, float bu, float bv, bool occluded,
                          Sink&& sink) {
   if (doS) {
@@ -676,7 +735,7 @@ DMT_DEV void lane_finish(KArgs k, PathState& st, bool doC, bool doS, int bestTri
   }
   sect_mark(3);
   if (doC) {
-    if (path_shade<ENV, AREA, TEX, LTREE>(k, st, bestTri, bu, bv)) {
+    if (path_shade<ENV, AREA, TEX, LTREE, BVH>(k, st, bestTri, bu, bv)) {
       st.active = false;
       if (st.hasShadow) {  // last NEE still untraced: park the sample, the lane may start the next
         put_Lfin(st.L);
@@ -1150,7 +1209,7 @@ DMT_DEV void flush_stats(KArgs Pk, LaneStats const& ls) {
   }
 }
 
-template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, int TEX = false, bool LTREE = false>
+template <bool BVH, bool STATS = false, bool ENV = false, bool AREA = false, int TEX = false, int LTREE = false>
 DMT_DEV void megakernel_body() {
   KArgs const Pk = kargs_base();
   LaneStats ls;
@@ -1210,7 +1269,7 @@ DMT_DEV void megakernel_body() {
 #ifndef DMT_BVH_DUMMY_LDS
 #define DMT_BVH_DUMMY_LDS 0  // occupancy experiments: extra LDS bytes per block (fewer resident blocks per CU)
 #endif
-template <bool STATS = false, bool ENV = false, bool AREA = false, int TEX = false, bool LTREE = false>
+template <bool STATS = false, bool ENV = false, bool AREA = false, int TEX = false, int LTREE = false>
 DMT_DEV void megakernel_body_bvh() {
   KArgs const Pk = kargs_base();
 #if DMT_BVH_DUMMY_LDS > 0
@@ -1226,12 +1285,7 @@ DMT_DEV void megakernel_body_bvh() {
   auto sink = [&](f3 L, uint32_t sidx) { stage_sample(Pk, sidx, L); };
   Traversal tv{};
   tv.phase = TR_IDLE;
-  {
-    BvhView const bvh0 = load_bvh(Pk);
-    tv.stack.ovf = bvh0.overflow + gtid;
-    tv.stack.stride = bvh0.overflowStride;
-    if constexpr (STATS) tv.stack.ovfCount = &ls.tc.overflowPushes;
-  }
+  if constexpr (STATS) tv.stack.ovfCount = &ls.tc.overflowPushes;
   {
     for (;;) {
       // A. draw + prepare units, start samples (only lanes between rounds start one)
@@ -1312,7 +1366,7 @@ DMT_DEV void megakernel_body_bvh() {
       if constexpr (STATS) ++ls.itShade, ls.lanesShade += tv.phase == TR_DONE ? 1u : 0u;
       if (tv.phase == TR_DONE) {
         if constexpr (STATS) ls.bounces += (tv.doC && tv.bestTri >= 0 && st.depth < kargs(Pk)->maxDepth) ? 1u : 0u;
-        lane_finish<ENV, AREA, TEX, LTREE>(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
+        lane_finish<ENV, AREA, TEX, LTREE, true>(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
         tv.phase = TR_IDLE;
       }
     }
@@ -1352,6 +1406,11 @@ __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_ltree(RenderParams P)
 __global__ void __launch_bounds__(256, 4) k_megakernel_env_ltree(RenderParams P) { megakernel_body<false, false, true, false, false, true>(); }
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_env_ltree(RenderParams P) { megakernel_body_bvh<false, true, false, false, true>(); }
 // both optional light kinds at once
+// the reference-semantics light tree (light_tree_ref.hpp): cuts of up to four lights per bounce
+__global__ void __launch_bounds__(256, 3) k_megakernel_ltree2(RenderParams P) { megakernel_body<false, false, false, false, false, 2>(); }
+__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_ltree2(RenderParams P) { megakernel_body_bvh<false, false, false, false, 2>(); }
+__global__ void __launch_bounds__(256, 3) k_megakernel_env_ltree2(RenderParams P) { megakernel_body<false, false, true, false, false, 2>(); }
+__global__ void __launch_bounds__(256, 2) k_megakernel_bvh_env_ltree2(RenderParams P) { megakernel_body_bvh<false, true, false, false, 2>(); }
 __global__ void __launch_bounds__(256, 4) k_megakernel_env_area(RenderParams P) { megakernel_body<false, false, true, true>(); }
 __global__ void __launch_bounds__(256, 3) k_megakernel_bvh_env_area(RenderParams P) { megakernel_body_bvh<false, true, true>(); }
 
@@ -1630,6 +1689,7 @@ struct dmt_ctx {
   int lightSampling = DMT_LIGHTS_UNIFORM;
   std::vector<uint8_t> h_lights;  // host copy of the packed light records
   LightTreeNode* d_lightTree = nullptr;
+  LightTreeRefNode* d_lightTreeRef = nullptr;  // DMT_LIGHTS_TREE_REFERENCE
   uint32_t lightTreeNodes = 0;
   int lightTreeDepth = 0;
   bool lightTreeValid = false;
@@ -1789,6 +1849,9 @@ SamplerParams computeSamplerParams(int width, int height) {
 }
 
 // the light tree applies to plain point / spot light lists; textured or emissive-triangle scenes keep the uniform pick
+bool useLightTreeRef(dmt_ctx const* c) {
+  return c->lightSampling == DMT_LIGHTS_TREE_REFERENCE && c->lightCount > 1 && c->lightsTreeable && c->areaCount == 0 && c->texCount == 0 && !c->hasBlend;
+}
 bool useLightTree(dmt_ctx const* c) {
   return c->lightSampling == DMT_LIGHTS_TREE && c->lightCount > 1 && c->lightsTreeable && c->areaCount == 0 && c->texCount == 0 && !c->hasBlend;
 }
@@ -1822,6 +1885,7 @@ RenderParams baseParams(dmt_ctx const* c, size_t threads) {
   P.areaOf = c->d_areaOf, P.areaTri = c->d_areaTri, P.areaLe = c->d_areaLe, P.areaCount = c->areaCount;
   if (c->texCount > 0) P.texRgba = c->d_texRgba, P.texDesc = c->d_texDesc, P.matTex = c->d_matTex, P.triUv = c->d_triUv;
   if (useLightTree(c) && c->lightTreeValid) P.lightTree = c->d_lightTree;
+  if (useLightTreeRef(c) && c->lightTreeValid) P.lightTreeRef = c->d_lightTreeRef;
   return P;
 }
 
@@ -1831,6 +1895,7 @@ MegakernelFn megakernelOf(dmt_ctx const* c) {
   bool const bvh = c->accel == DMT_ACCEL_BVH, env = c->env.w > 0, area = c->areaCount > 0, tex = c->texCount > 0;
   if (c->hasBlend) return bvh ? (env ? k_megakernel_bvh_env_blend : k_megakernel_bvh_blend) : (env ? k_megakernel_env_blend : k_megakernel_blend);
   if (tex) return bvh ? (env ? k_megakernel_bvh_env_tex : k_megakernel_bvh_tex) : (env ? k_megakernel_env_tex : k_megakernel_tex);
+  if (useLightTreeRef(c)) return bvh ? (env ? k_megakernel_bvh_env_ltree2 : k_megakernel_bvh_ltree2) : (env ? k_megakernel_env_ltree2 : k_megakernel_ltree2);
   if (useLightTree(c)) return bvh ? (env ? k_megakernel_bvh_env_ltree : k_megakernel_bvh_ltree) : (env ? k_megakernel_env_ltree : k_megakernel_ltree);
   if (area && env) return bvh ? k_megakernel_bvh_env_area : k_megakernel_env_area;
   if (area) return bvh ? k_megakernel_bvh_area : k_megakernel_area;
@@ -1909,9 +1974,46 @@ int buildBvh(dmt_ctx* ctx) {
   return DMT_OK;
 }
 
+// octahedral decode on the host (CC/private/encoding.cu:39-60), as pt_device.hpp's dir_from_octa
+void octa_host(uint32_t octa, float out[3]) {
+  float const mx = 65535.f;
+  float const fx = float(octa & 0xFFFFu) / mx * 2.f - 1.f, fy = float((octa >> 16) & 0xFFFFu) / mx * 2.f - 1.f;
+  float n[3] = {fx, fy, 1.f - fabsf(fx) - fabsf(fy)};
+  if (n[2] < 0.f) {
+    n[0] = (1.f - fabsf(fy)) * (std::signbit(fx) ? -1.f : 1.f);
+    n[1] = (1.f - fabsf(fx)) * (std::signbit(fy) ? -1.f : 1.f);
+  }
+  float const inv = 1.f / sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+  out[0] = n[0] * inv, out[1] = n[1] * inv, out[2] = n[2] * inv;
+}
+std::vector<LightTreeRefNode> buildLightTreeRef(uint8_t const* lights32, uint32_t count, int* depth, bool* ok) {
+  std::vector<light_tree_ref::Item> items;
+  *ok = true;
+  for (uint32_t i = 0; i < count; ++i) {
+    light_tree_ref::Item it{};
+    if (!light_tree_ref::itemOf(lights32 + 32 * size_t(i), i, [](uint16_t h) { return h2f_host(h); }, [](uint32_t o, float* d) { octa_host(o, d); }, it)) {
+      *ok = false;
+      return {};
+    }
+    items.push_back(it);
+  }
+  return light_tree_ref::build(items, depth);
+}
 // (re)build the light tree from the host copy of the light records and upload it
 int ensureLightTree(dmt_ctx* ctx) {
   if (ctx->lightTreeValid) return DMT_OK;
+  if (ctx->lightSampling == DMT_LIGHTS_TREE_REFERENCE) {
+    bool ok = true;
+    std::vector<LightTreeRefNode> const nodes = buildLightTreeRef(ctx->h_lights.data(), ctx->lightCount, &ctx->lightTreeDepth, &ok);
+    if (!ok) return fail(ctx, DMT_ERR_STATE, "light tree: only point and spot lights can be in the light list");
+    if (ctx->lightTreeDepth > kLightTreeRefMaxDepth) return fail(ctx, DMT_ERR_STATE, "light tree too deep");
+    int const rcR = devAlloc(ctx, &ctx->d_lightTreeRef, nodes.size());
+    if (rcR) return rcR;
+    if (!nodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_lightTreeRef, nodes.data(), nodes.size() * sizeof(LightTreeRefNode), hipMemcpyHostToDevice));
+    ctx->lightTreeNodes = uint32_t(nodes.size());
+    ctx->lightTreeValid = true;
+    return DMT_OK;
+  }
   std::vector<light_tree::Item> items;
   for (uint32_t i = 0; i < ctx->lightCount; ++i) {
     light_tree::Item it{};
@@ -2057,6 +2159,7 @@ int dmt_ctx_destroy(dmt_ctx* ctx) {
   (void)hipFree(ctx->d_trisBvh);
   (void)hipFree(ctx->d_overflow);
   (void)hipFree(ctx->d_lightTree);
+  (void)hipFree(ctx->d_lightTreeRef);
   (void)hipFree(ctx->d_texRgba);
   (void)hipFree(ctx->d_texDesc);
   (void)hipFree(ctx->d_matTex);
@@ -2227,7 +2330,9 @@ int dmt_set_accel(dmt_ctx* ctx, int mode) {
 
 int dmt_set_light_sampling(dmt_ctx* ctx, int mode) {
   if (!ctx) return DMT_ERR_INVALID;
-  if (mode != DMT_LIGHTS_UNIFORM && mode != DMT_LIGHTS_TREE) return fail(ctx, DMT_ERR_INVALID, "dmt_set_light_sampling: unknown mode");
+  if (mode != DMT_LIGHTS_UNIFORM && mode != DMT_LIGHTS_TREE && mode != DMT_LIGHTS_TREE_REFERENCE)
+    return fail(ctx, DMT_ERR_INVALID, "dmt_set_light_sampling: unknown mode");
+  if (mode != ctx->lightSampling) ctx->lightTreeValid = false;  // the two trees are different structures
   ctx->lightSampling = mode;
   return DMT_OK;
 }
@@ -2247,6 +2352,26 @@ int dmt_light_tree_pmfs(const void* lights32, uint32_t count, const float* p3, c
   light_tree::pmfs(nodes, p3, n3, pmf_out, count);
   if (node_count) *node_count = int(nodes.size());
   if (depth) *depth = d;
+  return DMT_OK;
+}
+
+// host only: cut + selection of the reference-semantics tree at n shading points (light_tree_ref.hpp's ltr_select, the
+// function the *_ltree2 kernels call)
+int dmt_light_tree_ref_select(const void* lights32, uint32_t count, int n, const float* p3, const float* n3, const float* u, float start_pmf,
+                              int32_t* indices4, float* pmfs4, int32_t* counts, int* node_count, int* depth) {
+  if ((count && !lights32) || n < 0 || (n && (!p3 || !n3 || !u || !indices4 || !pmfs4 || !counts))) return DMT_ERR_INVALID;
+  bool ok = true;
+  int d = 0;
+  std::vector<LightTreeRefNode> const nodes = buildLightTreeRef(static_cast<uint8_t const*>(lights32), count, &d, &ok);
+  if (!ok || nodes.empty()) return DMT_ERR_INVALID;
+  if (node_count) *node_count = int(nodes.size());
+  if (depth) *depth = d;
+  for (int i = 0; i < n; ++i) {
+    LightTreeRefSelection const sel = ltr_select(nodes.data(), p3[3 * i], p3[3 * i + 1], p3[3 * i + 2], n3[3 * i], n3[3 * i + 1], n3[3 * i + 2], u[i], start_pmf);
+    counts[i] = int32_t(sel.count);
+    for (int k = 0; k < kLightTreeMaxSplitSize; ++k)
+      indices4[4 * i + k] = k < int(sel.count) ? int32_t(sel.indices[k]) : -1, pmfs4[4 * i + k] = k < int(sel.count) ? sel.pmfs[k] : 0.f;
+  }
   return DMT_OK;
 }
 
@@ -2455,7 +2580,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   uint32_t const ownedTiles = P.numItems;
   // BVH launches run as the megakernel unless the wavefront form (wavefront.hpp) is asked for: on the measured scenes
   // the megakernel is faster (1 M triangles: 489 vs 378 Msamples/s), so "automatic" means megakernel
-  bool const wavefront = ctx->accel == DMT_ACCEL_BVH && ctx->bvhStrategy == 2 && ctx->texCount == 0 && !ctx->hasBlend && !useLightTree(ctx);  // textures / blends / light tree: megakernels only
+  bool const wavefront = ctx->accel == DMT_ACCEL_BVH && ctx->bvhStrategy == 2 && ctx->texCount == 0 && !ctx->hasBlend && !useLightTree(ctx) && !useLightTreeRef(ctx);  // textures / blends / light tree: megakernels only
   {  // fewer owned tiles than ~4 per resident wave: schedule row bands of the tiles instead of whole tiles
     uint32_t const waves = uint32_t(ctx->cuCount) * uint32_t(blocksPerCuOf(ctx)) * 4u;
     P.subShift = ctx->subShift >= 0 ? uint32_t(ctx->subShift) : 0u;
@@ -2490,6 +2615,10 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   if (useLightTree(ctx)) {
     if (int const rcT = ensureLightTree(ctx)) return rcT;
     P.lightTree = ctx->d_lightTree;
+  }
+  if (useLightTreeRef(ctx)) {
+    if (int const rcT = ensureLightTree(ctx)) return rcT;
+    P.lightTreeRef = ctx->d_lightTreeRef;
   }
   uint32_t const blocksNeeded = (wavesWanted + 3) / 4;
   if (blocks > blocksNeeded) blocks = blocksNeeded;

@@ -132,8 +132,6 @@ DMT_DEV void wf_trace_body(WfParams const& W) {
   Traversal tv{};
   tv.phase = TR_IDLE;
   tv.cur = kBvhEmpty;
-  tv.stack.ovf = bvh.overflow + gtid;
-  tv.stack.stride = bvh.overflowStride;
   uint32_t path = 0;
   // The wave draws CHUNKS of the queue with one atomic each and hands their entries to its lanes as they fall idle: one
   // shared cursor word saturates near 90 dequeues per microsecond on this chip (MI355X_MICROARCH.md, price list

@@ -98,7 +98,18 @@ int dmt_set_accel(dmt_ctx* ctx, int mode);
  * directional light in the list keep the uniform pick). */
 #define DMT_LIGHTS_UNIFORM 0
 #define DMT_LIGHTS_TREE 1
+/* the reference's light tree with its OWN semantics (src/core/public/core-light-tree-builder.h:17-104, .cpp:5-539): LightBounds with
+ * normal cone and emission falloff, lbImportance's orientation term, 32-bin summed-area-orientation splits, an adaptive cut of
+ * up to LightTreeMaxSplitSize = 4 nodes per shading point = up to four lights and four shadow rays per bounce
+ * (csrc/light_tree_ref.hpp lists what is kept as written and the four places that had to be corrected).  Same applicability
+ * rule as DMT_LIGHTS_TREE.  Unpinned by the reference (experimental, disabled code without outputs). */
+#define DMT_LIGHTS_TREE_REFERENCE 2
 int dmt_set_light_sampling(dmt_ctx* ctx, int mode);
+/* host only (no GPU): the cut + selection of DMT_LIGHTS_TREE_REFERENCE at n shading points p3 / n3 with one random number u each:
+ * up to four (light index, pmf) pairs per point (indices4 = -1 beyond counts[i]); start_pmf = probability that the light list
+ * (not the env map) was asked */
+int dmt_light_tree_ref_select(const void* lights32, uint32_t count, int n, const float* p3, const float* n3, const float* u, float start_pmf,
+                              int32_t* indices4, float* pmfs4, int32_t* counts, int* node_count, int* depth);
 /* host only (no GPU): probability of each of the `count` packed lights at point p3 with normal n3 under the tree */
 int dmt_light_tree_pmfs(const void* lights32, uint32_t count, const float* p3, const float* n3, float* pmf_out, int* node_count,
                         int* depth);

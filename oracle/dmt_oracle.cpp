@@ -1546,6 +1546,7 @@ struct Camera {  // CC/public/cuda-core/types.cuh:101-109 (44 bytes)
 static_assert(sizeof(Camera) == 44, "DeviceCamera layout");
 
 struct LtNode;
+struct LtrNode;
 struct Scene {
   float const* xs;  // float4 per triangle
   float const* ys;
@@ -1575,6 +1576,7 @@ struct Scene {
   float const* triUv = nullptr;
   // light tree (see "light tree" below); null = the megakernel's uniform pick
   LtNode const* lightTree = nullptr;
+  LtrNode const* lightTreeRef = nullptr;  // lightSampling == 2: the reference's tree (cones, SAOH, cuts of up to four lights)
 };
 
 struct Stats {  // algorithmic work counters (SURVEY 8d byte model)
@@ -1796,6 +1798,305 @@ inline void ltPmfs(std::vector<LtNode> const& nodes, V3 p, V3 n, float* out, uin
     stack.push_back({nd.ref, w.second * p0});
     stack.push_back({nd.ref + 1u, w.second * (1.f - p0)});
   }
+}
+
+// ---- the reference's light tree with its own semantics (lightSampling == 2) --------------------------------------
+// Restates src/core/private/core-light-tree-builder.cpp: directionConesUnion :5-49, lbUnion :52-69, cosSubClamped /
+// sinSubClamped / sinCosThetaBoundsSubtended :77-96, lbImportance :98-146, makeLBFromLight :149-187,
+// adaptiveSplittingHeuristic :190-232, lightTreeBounds_Kr / _Ma / _Momega and summedAreaOrientationHeuristic :235-283,
+// lightTreeBuildRecursive :305-392, lightTreeComputeVariances :394-426, lightTreeAdaptiveSplit :448-491,
+// selectLightsFromSplit :493-539 (sampleDiscrete: core-math.cu:366-392); constants core-light-tree-builder.h:62-65.
+// Kept as written: cosTheta_e of a union = fmaxf (:63), distances clamped against the half diagonal's LENGTH (:112, :202),
+// M_omega's "cosTheta_diff" being a sine (:254), twoSided = false, the pow(., 1/4).  Four places where the written code is
+// undefined or defeats itself are corrected exactly as the product documents them (csrc/light_tree_ref.hpp, [fix 1..4]):
+// bins filled from the node's own lights, split planes offset by the node's lower bound, both children always present with
+// the bounds of their own lights, |centre - p|^2 in the bounding-sphere test.  evalFac = 1 / pi (core-light.h:134-140).
+// Experimental and disabled in the reference, no output to compare with: PARITY UNPINNED.
+struct LtrBounds {
+  V3 lo, hi, w;
+  float cosTheta_o, cosTheta_e, phi;
+  bool empty;
+};
+struct LtrNode {
+  LtrBounds lb;
+  float varPhi = 0.f;
+  uint32_t numEmitters = 0, left = 0, light = 0;  // light: 0x80000000 | index for a leaf
+  bool leaf() const { return (light & 0x80000000u) != 0u; }
+};
+inline float ltrSafeSqrt(float x) { return sqrtf(fmaxf(0.f, x)); }
+inline float ltrSafeAcos(float x) { return acosf(fminf(fmaxf(x, -1.f), 1.f)); }
+inline LtrBounds ltrEmpty() {
+  LtrBounds b{};
+  b.lo = v3(INFINITY, INFINITY, INFINITY), b.hi = v3(-INFINITY, -INFINITY, -INFINITY), b.empty = true;
+  return b;
+}
+inline LtrBounds ltrFromLight(Rec32 const& L) {  // :149-187
+  float const evalFac = 1.f / kPi;
+  V3 const c = rdh3(L, L_INT);
+  float const strength = 0.2126f * c.x + 0.7152f * c.y + 0.0722f * c.z;
+  V3 const co = rdf3(L, LP_POS);
+  LtrBounds b{};
+  if (rd16(L, L_TYPE) == LT_POINT) {
+    float const r = fmaxf(h2f(rd16(L, LP_RAD)), 0.f);
+    b.lo = co - v3(r, r, r), b.hi = co + v3(r, r, r);
+    b.phi = 4.f * kPi * strength * evalFac;
+    b.w = v3(0, 0, 1), b.cosTheta_o = -1.f, b.cosTheta_e = 0.f;
+  } else {
+    float const r = fmaxf(h2f(rd16(L, LS_RAD)), 0.f);
+    float const cos0 = fminf(fmaxf(h2f(rd16(L, LS_COS0)), -1.f), 1.f), cosE = fminf(fmaxf(h2f(rd16(L, LS_COSE)), -1.f), 1.f);
+    b.lo = co - v3(r, r, r), b.hi = co + v3(r, r, r);
+    b.phi = 2.f * kPi * (1.f - cosE) * evalFac * strength;
+    b.cosTheta_e = cosf(ltrSafeAcos(cosE) - ltrSafeAcos(cos0));
+    b.w = dirFromOcta(rd32(L, LS_DIR));
+    b.cosTheta_o = cos0;
+  }
+  return b;
+}
+inline void ltrConesUnion(V3 w0, float c0, V3 w1, float c1, V3* w, float* c) {  // :5-49
+  float const t0 = ltrSafeAcos(c0), t1 = ltrSafeAcos(c1);
+  float const td = ltrSafeAcos(dot(w0, w1));  // angleBetween of two unit vectors
+  auto all = [](V3 v) { return v.x != 0.f && v.y != 0.f && v.z != 0.f; };
+  if ((std::isnan(td) && !all(w1)) || fminf(td + t1, kPi) <= t0) {
+    *w = w0, *c = c0;
+    return;
+  }
+  if ((std::isnan(td) && !all(w0)) || fminf(td + t0, kPi) <= t1) {
+    *w = w1, *c = c1;
+    return;
+  }
+  float const tc = (t0 + td + t1) * 0.5f;
+  V3 r = cross(w0, w1);
+  float const rl2 = dot(r, r);
+  if (tc >= kPi || !(rl2 > 0.f)) {
+    *w = v3(0, 0, 1), *c = -1.f;
+    return;
+  }
+  r = r * (1.f / sqrtf(rl2));
+  float const a = tc - t0, ca = cosf(a), sa = sinf(a);  // rotation of w0 about r by a (fromRadians + rotate)
+  V3 const rxw = cross(r, w0);
+  float const rdw = dot(r, w0);
+  V3 const v = w0 * ca + rxw * sa + r * (rdw * (1.f - ca));
+  *w = v * (1.f / sqrtf(dot(v, v)));
+  *c = cosf(tc);
+}
+inline LtrBounds ltrUnion(LtrBounds const& a, LtrBounds const& b) {  // :52-69
+  if (a.empty) return b;
+  if (b.empty) return a;
+  LtrBounds u{};
+  u.lo = v3(fminf(a.lo.x, b.lo.x), fminf(a.lo.y, b.lo.y), fminf(a.lo.z, b.lo.z));
+  u.hi = v3(fmaxf(a.hi.x, b.hi.x), fmaxf(a.hi.y, b.hi.y), fmaxf(a.hi.z, b.hi.z));
+  ltrConesUnion(a.w, a.cosTheta_o, b.w, b.cosTheta_o, &u.w, &u.cosTheta_o);
+  u.cosTheta_e = fmaxf(a.cosTheta_e, b.cosTheta_e);
+  u.phi = a.phi + b.phi;
+  return u;
+}
+inline float ltrArea(LtrBounds const& b) {
+  V3 const d = b.hi - b.lo;
+  return 2.f * (d.x * d.y + d.x * d.z + d.y * d.z);
+}
+inline float ltrMomega(float cosTheta_e, float cosTheta_o) {  // :247-263
+  float const theta_e = ltrSafeAcos(cosTheta_e), theta_o = ltrSafeAcos(cosTheta_o);
+  float const theta_w = fminf(theta_o + theta_e, kPi);
+  float const sinTheta_o = sinf(theta_o);
+  float const cosTheta_diff = sinf(theta_o - 2.f * theta_w);
+  return 2.f * kPi * (1.f - cosTheta_o) + (kPi / 2.f) * (2.f * theta_w * sinTheta_o - cosTheta_diff - 2.f * theta_o * sinTheta_o + cosTheta_o);
+}
+inline float ltrCosSub(float sa, float ca, float sb, float cb) { return ca > cb ? 1.f : ca * cb + sa * sb; }
+inline float ltrSinSub(float sa, float ca, float sb, float cb) { return ca > cb ? 0.f : sa * cb - ca * sb; }
+inline float ltrImportance(LtrBounds const& lb, V3 p, V3 n) {  // :98-146
+  V3 const pc = (lb.lo + lb.hi) / 2.f;
+  V3 const d = p - pc;
+  float const len2 = dot(d, d);
+  V3 const wi = d * (1.f / sqrtf(len2));
+  float const sinTheta_o = ltrSafeSqrt(1.f - lb.cosTheta_o * lb.cosTheta_o);
+  V3 const e = lb.hi - lb.lo;
+  float const distSqr = fmaxf(len2, sqrtf(dot(e, e)) * 0.5f);
+  float const cosTheta_w = dot(wi, lb.w);
+  float const sinTheta_w = ltrSafeSqrt(1.f - cosTheta_w * cosTheta_w);
+  V3 const h = lb.hi - pc;
+  float const radius2 = dot(h, h);
+  float sinTheta_b = 0.f, cosTheta_b = -1.f;
+  if (!(len2 < radius2)) {
+    float const s2 = radius2 / len2;
+    sinTheta_b = sqrtf(s2), cosTheta_b = ltrSafeSqrt(1.f - s2);
+  }
+  float const cosTheta_wo = ltrCosSub(sinTheta_w, cosTheta_w, sinTheta_o, lb.cosTheta_o);
+  float const sinTheta_wo = ltrSinSub(sinTheta_w, cosTheta_w, sinTheta_o, lb.cosTheta_o);
+  float const cosTheta_p = ltrCosSub(sinTheta_wo, cosTheta_wo, sinTheta_b, cosTheta_b);
+  if (cosTheta_p <= lb.cosTheta_e) return 0.f;
+  float const cosTheta_i = fabsf(dot(wi, n));
+  float const sinTheta_i = ltrSafeSqrt(1.f - cosTheta_i * cosTheta_i);
+  float const cosTheta_ib = ltrCosSub(sinTheta_i, cosTheta_i, sinTheta_b, cosTheta_b);
+  return fmaxf(lb.phi * cosTheta_ib * cosTheta_p / distSqr, 0.f);
+}
+inline float ltrSplitHeuristic(LtrNode const& nd, V3 p) {  // :190-232
+  if (nd.leaf()) return 1.f;
+  V3 const pc = (nd.lb.lo + nd.lb.hi) / 2.f;
+  V3 const d = p - pc, e = nd.lb.hi - nd.lb.lo;
+  float const halfDiag = sqrtf(dot(e, e)) * 0.5f;
+  float const dist = ltrSafeSqrt(fmaxf(dot(d, d), halfDiag));
+  float const a = fmaxf(dist - halfDiag, 0.f), b = dist + halfDiag;
+  float gExpected2 = 0.f, gVariance = 0.f;
+  if (a > 0.f && b > 0.f) {
+    float const a3 = a * a * a, b3 = b * b * b;
+    float const a_minus_b = a - b;
+    float const a3_minus_b3 = a_minus_b * (a * a + a * b + b * b);
+    float const r = 1.f / (a * b);
+    gExpected2 = r * r;
+    gVariance = a3_minus_b3 / (3.f * a_minus_b * a3 * b3) - gExpected2;
+  }
+  float const n = float(nd.numEmitters);
+  float const eMean = nd.lb.phi / n;
+  float const eExpected2 = eMean * eMean, eVariance = nd.varPhi;
+  float const sigma2 = (eVariance * gVariance + eVariance * gExpected2 + eExpected2 * gVariance) * (n * n);
+  return sqrtf(sqrtf(fmaxf(1.f / (1.f + sqrtf(sigma2)), 0.f)));
+}
+inline std::vector<LtrNode> ltrBuild(Rec32 const* lights, uint32_t count) {  // :305-446
+  std::vector<uint32_t> order;
+  for (uint32_t i = 0; i < count; ++i)
+    if (rd16(lights[i], L_TYPE) == LT_POINT || rd16(lights[i], L_TYPE) == LT_SPOT) order.push_back(i);
+  std::vector<LtrNode> nodes;
+  if (order.empty()) return nodes;
+  auto rangeBounds = [&](size_t a, size_t b) {
+    LtrBounds lb = ltrEmpty();
+    for (size_t i = a; i < b; ++i) lb = ltrUnion(lb, ltrFromLight(lights[order[i]]));
+    return lb;
+  };
+  struct Work {
+    uint32_t node;
+    size_t a, b;
+    LtrBounds lb;
+  };
+  nodes.emplace_back();
+  std::vector<Work> stack{{0u, 0, order.size(), rangeBounds(0, order.size())}};
+  while (!stack.empty()) {
+    Work const w = stack.back();
+    stack.pop_back();
+    nodes[w.node].lb = w.lb;
+    size_t const n = w.b - w.a;
+    nodes[w.node].numEmitters = uint32_t(n);
+    if (n == 1) {
+      nodes[w.node].light = 0x80000000u | order[w.a];
+      continue;
+    }
+    V3 const d = w.lb.hi - w.lb.lo;
+    int const axis = (d.x > d.y && d.x > d.z) ? 0 : (d.y > d.z ? 1 : 2);
+    auto comp = [axis](V3 v) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); };
+    float const splitLen = comp(d) / 32.f;
+    float const Kr = fmaxf(d.x, fmaxf(d.y, d.z)) / comp(d);
+    float const Ma = ltrArea(w.lb), Mo = ltrMomega(w.lb.cosTheta_e, w.lb.cosTheta_o);
+    LtrBounds bestL = ltrEmpty(), bestR = ltrEmpty();
+    float minSplitPos = 0.f, minCost = INFINITY;
+    bool found = false;
+    for (int i = 1; i < 31; ++i) {
+      float const splitPos = comp(w.lb.lo) + float(i) * splitLen;
+      LtrBounds L = ltrEmpty(), R = ltrEmpty();
+      for (size_t k = w.a; k < w.b; ++k) {
+        Rec32 const& light = lights[order[k]];
+        if (comp(rdf3(light, LP_POS)) < splitPos) L = ltrUnion(L, ltrFromLight(light));
+        else R = ltrUnion(R, ltrFromLight(light));
+      }
+      if (L.empty || R.empty) continue;
+      float const cost = Kr * (L.phi * ltrArea(L) * ltrMomega(L.cosTheta_e, L.cosTheta_o) + R.phi * ltrArea(R) * ltrMomega(R.cosTheta_e, R.cosTheta_o)) / (Ma * Mo);
+      if (cost < minCost) minCost = cost, minSplitPos = splitPos, bestL = L, bestR = R, found = true;
+    }
+    size_t mid;
+    if (found) {
+      mid = size_t(std::stable_partition(order.begin() + long(w.a), order.begin() + long(w.b),
+                                         [&](uint32_t li) { return comp(rdf3(lights[li], LP_POS)) < minSplitPos; }) - order.begin());
+    } else {
+      mid = w.a + n / 2;
+      bestL = rangeBounds(w.a, mid), bestR = rangeBounds(mid, w.b);
+    }
+    uint32_t const left = uint32_t(nodes.size());
+    nodes.emplace_back(), nodes.emplace_back();
+    nodes[w.node].left = left;
+    stack.push_back({left + 1u, mid, w.b, bestR});
+    stack.push_back({left, w.a, mid, bestL});
+  }
+  for (size_t i = 0; i < nodes.size(); ++i) {  // :394-426
+    if (nodes[i].leaf()) continue;
+    std::vector<float> phis;
+    std::vector<uint32_t> st{uint32_t(i)};
+    while (!st.empty()) {
+      uint32_t const at = st.back();
+      st.pop_back();
+      if (nodes[at].leaf()) {
+        phis.push_back(nodes[at].lb.phi);
+        continue;
+      }
+      st.push_back(nodes[at].left + 1u), st.push_back(nodes[at].left);
+    }
+    float mean = 0.f, var = 0.f;
+    for (float f : phis) mean += f;
+    mean /= float(phis.size());
+    for (float f : phis) var += (f - mean) * (f - mean);
+    nodes[i].varPhi = var / float(phis.size() - 1);
+  }
+  return nodes;
+}
+struct LtrSelection {
+  uint32_t indices[4];
+  float pmfs[4];
+  uint32_t count = 0;
+};
+inline LtrSelection ltrSelect(LtrNode const* nodes, V3 p, V3 n, float u, float startPMF, float precision = 0.5f) {
+  // lightTreeAdaptiveSplit :448-491
+  std::vector<uint32_t> cut;
+  if (nodes[0].leaf()) {
+    cut.push_back(0u);
+  } else {
+    std::vector<uint32_t> parentStack, siblingStack{0u};
+    while ((!siblingStack.empty() || !parentStack.empty()) && cut.size() < 4) {
+      if (!siblingStack.empty()) {
+        uint32_t const sibling = siblingStack.back();
+        siblingStack.pop_back();
+        bool const enough = ltrSplitHeuristic(nodes[sibling], p) >= precision;
+        if (cut.size() + 1 == 4 || enough) cut.push_back(sibling);
+        else if (!nodes[sibling].leaf()) parentStack.push_back(sibling);
+      } else {
+        uint32_t const parent = parentStack.back();
+        parentStack.pop_back();
+        siblingStack.push_back(nodes[parent].left), siblingStack.push_back(nodes[parent].left + 1u);
+      }
+    }
+  }
+  // selectLightsFromSplit :493-539
+  LtrSelection sel;
+  uint32_t moreLights = uint32_t(cut.size()), splitIndex = 0;
+  while (sel.count < cut.size() && moreLights && splitIndex < cut.size()) {
+    uint32_t at = cut[splitIndex++];
+    float pmf = startPMF;
+    bool pathSampled = false;
+    while (!pathSampled) {
+      LtrNode const& nd = nodes[at];
+      if (!nd.leaf()) {
+        float const w[2] = {ltrImportance(nodes[nd.left].lb, p, n), ltrImportance(nodes[nd.left + 1u].lb, p, n)};
+        if (w[0] == 0.f && w[1] == 0.f) {
+          pathSampled = true;
+        } else {  // sampleDiscrete, core-math.cu:366-392
+          float const sumWeights = w[0] + w[1];
+          float up = u * sumWeights;
+          if (up == sumWeights) up = nextafterf(up, -INFINITY);
+          int offset = 0;
+          float sum = 0.f;
+          while (offset < 1 && sum + w[offset] <= up) sum += w[offset], ++offset;
+          pmf *= w[offset] / sumWeights;
+          u = fminf((up - sum) / w[offset], 0.99999994f);
+          at = nd.left + uint32_t(offset);
+        }
+      } else {
+        pathSampled = true;
+        --moreLights;
+        if (ltrImportance(nd.lb, p, n) > 0.f) {
+          sel.indices[sel.count] = nd.light & 0x7FFFFFFFu;
+          sel.pmfs[sel.count] = pmf;
+          ++sel.count;
+        }
+      }
+    }
+  }
+  return sel;
 }
 
 // ---- image textures ------------------------------------------------------------------------------
@@ -2057,6 +2358,38 @@ V3 tracePath(Scene const& sc, RenderCfg const& cfg, int px, int py, int s, Stats
           if (!isZero(f) && maxComponent(Le) > 0.f) L += beta * (Le * f / (es.pdf * 0.5f + bsdfPdf));
         }
       }
+    } else if (sc.lightTreeRef && sc.lightCount > 1 && sc.areaCount == 0 && !sc.matTex) {
+      // lightSampling == 2: a cut of up to four tree nodes, one light drawn below each, one shadow ray per light
+      // (core-render.cpp:296-370); the contribution of each light is this path's own NEE term with the light's pmf
+      LtrSelection const sel = ltrSelect(sc.lightTreeRef, hit.pos, hit.normal, uLight, sc.env ? 0.5f : 1.f);
+      for (uint32_t i = 0; i < sel.count; ++i) {
+        Rec32 const& light = sc.lights[sel.indices[i]];
+        float const lightPMF = sel.pmfs[i];
+        LightSample const ls = sampleLight(light, hit.pos, uLight2, lastBounceTransmission, hit.normal);
+        if (!ls.valid()) continue;
+        Ray const shadow{offsetRayOrigin(hit.pos, hit.error, hit.normal, ls.direction), ls.direction};
+        bool doNEE = true;
+        if (st) st->shadowRays++;
+        for (uint64_t tri = 0; tri < sc.triCount; ++tri) {
+          if (st) st->triTests++;
+          Hit const r = triangleIntersect(sc.xs + 4 * tri, sc.ys + 4 * tri, sc.zs + 4 * tri, shadow);
+          if (r.hit && r.t < ls.distance) {
+            doNEE = false;
+            break;
+          }
+        }
+        if (!doNEE) continue;
+        float bsdfPdf = 0;
+        V3 const f = evalMaterial(-ray.d, shadow.d, &bsdfPdf);
+        V3 const Le = evalLight(light, ls);
+        if (isZero(f)) continue;
+        if (ls.delta) {
+          L += beta * Le * f / lightPMF;
+        } else {
+          float const w = sqrf(lightPMF * ls.pdf) / sqrf(lightPMF * ls.pdf + bsdfPdf);
+          L += Le * f * beta * w;
+        }
+      }
     } else if (sc.lightCount > 0) {
       uint32_t li = sc.areaCount > 0 ? pickIndex(uLight, sc.lightCount + sc.areaCount) : pickIndex(uLight, sc.lightCount);
       float lightPMF = (sc.env ? 0.5f : 1.f) / float(sc.lightCount + sc.areaCount);
@@ -2315,11 +2648,11 @@ struct OracleScene {  // mirrors include/dmt_hip.h's upload calls
   uint32_t texCount;
   const uint32_t* matTex;
   const float* triUv;
-  int32_t lightSampling;  // 0 = uniform pick, 1 = light tree
+  int32_t lightSampling;  // 0 = uniform pick, 1 = light tree (reduced: one light), 2 = the reference's tree (cuts of up to four lights)
 };
 
 static Scene toScene(OracleScene const* s, EnvMap* envStorage = nullptr, std::vector<uint32_t>* areaStorage = nullptr,
-                     std::vector<LtNode>* treeStorage = nullptr) {
+                     std::vector<LtNode>* treeStorage = nullptr, std::vector<LtrNode>* refTreeStorage = nullptr) {
   Scene sc;
   if (areaStorage && s->areaCount > 0 && s->areaTri && s->areaLe) {
     areaStorage->assign(size_t(s->triCount), 0xFFFFFFFFu);
@@ -2341,6 +2674,10 @@ static Scene toScene(OracleScene const* s, EnvMap* envStorage = nullptr, std::ve
     *treeStorage = ltBuild(sc.lights, sc.lightCount);
     if (!treeStorage->empty()) sc.lightTree = treeStorage->data();
   }
+  if (refTreeStorage && s->lightSampling == 2 && s->lightCount > 1) {
+    *refTreeStorage = ltrBuild(sc.lights, sc.lightCount);
+    if (!refTreeStorage->empty()) sc.lightTreeRef = refTreeStorage->data();
+  }
   return sc;
 }
 
@@ -2349,6 +2686,20 @@ int oracle_light_tree_pmfs(const void* lights32, uint32_t count, const float* p3
   std::vector<LtNode> const nodes = ltBuild(reinterpret_cast<Rec32 const*>(lights32), count);
   ltPmfs(nodes, v3(p3[0], p3[1], p3[2]), v3(n3[0], n3[1], n3[2]), out, count);
   if (nodeCount) *nodeCount = int(nodes.size());
+  return 0;
+}
+
+// the reference-semantics tree at n shading points: up to four (light index, pmf) pairs each, plus the tree's shape
+int oracle_light_tree_ref_select(const void* lights32, uint32_t count, int n, const float* p3, const float* n3, const float* u, float startPMF,
+                                 int32_t* indices4, float* pmfs4, int32_t* counts, int* nodeCount) {
+  std::vector<LtrNode> const nodes = ltrBuild(reinterpret_cast<Rec32 const*>(lights32), count);
+  if (nodeCount) *nodeCount = int(nodes.size());
+  if (nodes.empty()) return -1;
+  for (int i = 0; i < n; ++i) {
+    LtrSelection const sel = ltrSelect(nodes.data(), v3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), v3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), u[i], startPMF);
+    counts[i] = int32_t(sel.count);
+    for (int k = 0; k < 4; ++k) indices4[4 * i + k] = k < int(sel.count) ? int32_t(sel.indices[k]) : -1, pmfs4[4 * i + k] = k < int(sel.count) ? sel.pmfs[k] : 0.f;
+  }
   return 0;
 }
 
@@ -2573,7 +2924,8 @@ int oracle_render(const OracleScene* s, const void* camera44, int maxDepth, int 
   EnvMap env;
   std::vector<uint32_t> areaOf;
   std::vector<LtNode> lightTree;
-  Scene const sc = toScene(s, &env, &areaOf, &lightTree);
+  std::vector<LtrNode> lightTreeRef;
+  Scene const sc = toScene(s, &env, &areaOf, &lightTree, &lightTreeRef);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   if (x0 < 0) x0 = 0;
   if (y0 < 0) y0 = 0;
@@ -2625,7 +2977,8 @@ void oracle_trace_samples(const OracleScene* s, const void* camera44, int maxDep
   EnvMap env;
   std::vector<uint32_t> areaOf;
   std::vector<LtNode> lightTree;
-  Scene const sc = toScene(s, &env, &areaOf, &lightTree);
+  std::vector<LtrNode> lightTreeRef;
+  Scene const sc = toScene(s, &env, &areaOf, &lightTree, &lightTreeRef);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   for (int i = 0; i < n; ++i) {
     V3 const L = tracePath(sc, cfg, pxs[i], pys[i], ss[i], nullptr);
@@ -2641,7 +2994,8 @@ int oracle_trace_log(const OracleScene* s, const void* camera44, int maxDepth, i
   EnvMap env;
   std::vector<uint32_t> areaOf;
   std::vector<LtNode> lightTree;
-  Scene const sc = toScene(s, &env, &areaOf, &lightTree);
+  std::vector<LtrNode> lightTreeRef;
+  Scene const sc = toScene(s, &env, &areaOf, &lightTree, &lightTreeRef);
   RenderCfg const cfg = makeCfg(cam, maxDepth, rtlArgs);
   PathLog log;
   log.rec = rec12, log.cap = cap;

@@ -417,3 +417,22 @@ def light_tree_pmfs(lights32, p, n):
                                  _p(np.ascontiguousarray(n, np.float32)), _p(out), C.byref(nc))
     return out, nc.value
 
+
+
+def light_tree_ref_select(lights32, p, n, u, start_pmf=1.0):
+    """the reference-semantics tree (cones, SAOH, cuts of up to four nodes) at shading points p [k,3] with
+    normals n [k,3] and one random number each: (indices [k,4] (-1 = none), pmfs [k,4], counts [k], node count)."""
+    L = np.ascontiguousarray(lights32, np.uint8).reshape(-1, 32)
+    p = np.ascontiguousarray(p, np.float32).reshape(-1, 3)
+    n = np.ascontiguousarray(n, np.float32).reshape(-1, 3)
+    u = np.ascontiguousarray(u, np.float32).reshape(-1)
+    k = p.shape[0]
+    idx = np.zeros((k, 4), np.int32)
+    pmf = np.zeros((k, 4), np.float32)
+    cnt = np.zeros(k, np.int32)
+    nc = C.c_int()
+    rc = lib().oracle_light_tree_ref_select(_p(L), C.c_uint32(L.shape[0]), C.c_int(k), _p(p), _p(n), _p(u), C.c_float(start_pmf),
+                                            _p(idx), _p(pmf), _p(cnt), C.byref(nc))
+    if rc != 0:
+        raise ValueError("oracle_light_tree_ref_select: no point / spot lights")
+    return idx, pmf, cnt, nc.value

@@ -64,3 +64,65 @@ def test_degenerate_layouts(pkg, O):
         assert nodes == 17 and abs(float(a.sum()) - 1.0) < 1e-5 and np.allclose(a, b, rtol=1e-5, atol=1e-9)
     a, nodes, depth = pkg.light_tree_pmfs(L[:1], [0, 0, 0], [0, 1, 0])
     assert nodes == 1 and depth == 1 and a.tolist() == [1.0]
+
+
+# ---- DMT_LIGHTS_TREE_REFERENCE: the reference's tree with its own semantics (csrc/light_tree_ref.hpp) --------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 301])
+def test_reference_tree_selection_matches_the_oracle(pkg, O, n):
+    """The product's builder + cut + selection (the function the *_ltree2 kernels call, run on the host) against the oracle's
+    own restatement of core-light-tree-builder.cpp: same cut size, same lights, same probabilities; up to
+    LightTreeMaxSplitSize = 4 lights per shading point, each with pmf <= start pmf."""
+    L = _lights(pkg, n, 1000 + n)
+    rng = np.random.default_rng(7 + n)
+    k = 256
+    p = rng.uniform(-5, 5, (k, 3)) + [0, 6, 0]
+    nrm = rng.normal(size=(k, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    u = rng.uniform(0, 1, k).astype(np.float32)
+    for start in (1.0, 0.5):
+        ai, ap, ac, nodes, depth = pkg.light_tree_ref_select(L, p, nrm, u, start)
+        bi, bp, bc, onodes = O.light_tree_ref_select(L, p, nrm, u, start)
+        assert nodes == onodes == 2 * n - 1 and depth <= 60
+        assert np.array_equal(ac, bc) and np.array_equal(ai, bi)
+        assert np.allclose(ap, bp, rtol=2e-5, atol=1e-9)
+        assert ac.max() <= 4 and (ap <= start * (1 + 1e-6)).all()
+        valid = np.arange(4)[None, :] < ac[:, None]
+        assert (ap[valid] > 0).all() and (ai[valid] >= 0).all() and (ai[valid] < n).all() and (ai[~valid] == -1).all()
+        for row, c in zip(ai, ac):                      # the walks below different cut nodes end in different lights
+            assert len(set(row[:c].tolist())) == c
+    if n >= 17:
+        assert ac.max() >= 2                            # the adaptive cut really splits somewhere
+
+
+def test_reference_tree_orientation_term(pkg):
+    """lbImportance's cone test (core-light-tree-builder.cpp:124-130): a shading point BEHIND a spot light (outside its
+    emission falloff) gives that light importance 0 -- it is never selected there -- while a point light next to it is."""
+    import ctypes as C
+    H = pkg.host_scene.load_host_library()
+    f3 = lambda v: np.ascontiguousarray(v, np.float32).ctypes.data_as(C.c_void_p)
+    spot, point = np.zeros(32, np.uint8), np.zeros(32, np.uint8)
+    H.dmt_host_make_spot_light(f3([5, 5, 5]), f3([0, 0, 0]), f3([0, 0, -1]), C.c_float(0.95), C.c_float(0.8), C.c_float(0.01), spot.ctypes.data_as(C.c_void_p))
+    H.dmt_host_make_point_light(f3([1, 1, 1]), f3([3, 0, 0]), C.c_float(0.01), point.ctypes.data_as(C.c_void_p))
+    L = np.stack([spot, point])
+    u = np.linspace(0.01, 0.99, 64).astype(np.float32)
+    below = np.tile([0.0, 0.0, -4.0], (64, 1))           # in the cone's axis
+    above = np.tile([0.0, 0.0, 4.0], (64, 1))            # behind the spot light
+    up = np.tile([0.0, 0.0, 1.0], (64, 1))
+    bi, _, bc, _, _ = pkg.light_tree_ref_select(L, below, up, u)
+    ai, _, ac, _, _ = pkg.light_tree_ref_select(L, above, -up, u)
+    assert (bi[np.arange(4)[None, :] < bc[:, None]] == 0).any()
+    assert not (ai[np.arange(4)[None, :] < ac[:, None]] == 0).any() and (ai[:, 0] == 1).all()
+
+
+def test_reference_tree_degenerate_layouts(pkg, O):
+    L = _lights(pkg, 9, 1)
+    same = L.copy()
+    same[:, 8:20] = same[0, 8:20]                                           # all lights at one point: no plane separates them
+    rng = np.random.default_rng(3)
+    p = rng.uniform(-3, 3, (32, 3)) + [0, 6, 0]
+    nrm = np.tile([0.0, -1.0, 0.0], (32, 1))
+    u = rng.uniform(0, 1, 32).astype(np.float32)
+    ai, ap, ac, nodes, depth = pkg.light_tree_ref_select(same, p, nrm, u)
+    bi, bp, bc, onodes = O.light_tree_ref_select(same, p, nrm, u)
+    assert nodes == onodes == 17 and np.array_equal(ai, bi) and np.array_equal(ac, bc) and np.allclose(ap, bp, rtol=2e-5, atol=1e-9)
+    assert np.isfinite(ap).all()

@@ -1251,6 +1251,43 @@ def test_light_tree_film_vs_oracle(renderer, pkg, O, accel, env):
     assert float(m2[..., :3].mean()) < 0.6 * float(um2[..., :3].mean()), (float(m2[..., :3].mean()), float(um2[..., :3].mean()), stderr_u)
 
 
+@pytest.mark.parametrize("accel, env", [(0, False), (1, False), (0, True), (1, True)])
+def test_reference_light_tree_film_vs_oracle(renderer, pkg, O, accel, env):
+    """DMT_LIGHTS_TREE_REFERENCE (csrc/light_tree_ref.hpp): the reference's tree with its own semantics --
+    normal cones, orientation term, SAOH splits, adaptive cuts of up to FOUR lights = up to four shadow rays per bounce --
+    in the *_ltree2 kernels against the oracle's own restatement, 64 lights.  All but the last selected light of a bounce
+    are shadow-tested in line (brute force: a triangle pass; BVH: a whole any-hit traversal).  Parity unpinned by the
+    reference (experimental code without outputs): oracle <-> HIP."""
+    sc = _many_lights_cornell(O, pkg, 64, env=env)
+    sc.light_sampling = 2
+    renderer.upload_scene(sc)
+    renderer.set_limits(5)
+    renderer.set_accel(accel)
+    renderer.set_partition(0, 1)
+    try:
+        renderer.set_light_sampling(2)
+        renderer.film_clear()
+        renderer.render(32)
+        renderer.sync()
+        mean, m2 = renderer.download_film()
+        renderer.set_light_sampling(1)
+        renderer.film_clear()
+        renderer.render(32)
+        renderer.sync()
+        smean, sm2 = renderer.download_film()
+    finally:
+        renderer.set_light_sampling(0)
+        renderer.set_accel(0)
+        renderer.clear_envmap()
+    om, om2 = O.render(sc, 32, max_depth=5, threads=8)[:2]
+    assert np.array_equal(m2[..., 3], om2[..., 3]) and np.isfinite(mean).all()
+    scale = float(om[..., :3].mean())
+    assert scale > 0.01
+    assert film_rmse(mean, om) < RMSE_TOL * max(1.0, scale), film_rmse(mean, om)
+    # several lights per bounce: less variance than the single-light tree on the same scene
+    assert float(m2[..., :3].mean()) < float(sm2[..., :3].mean()), (float(m2[..., :3].mean()), float(sm2[..., :3].mean()))
+
+
 def test_light_tree_converges_to_the_uniform_image(renderer, pkg, O):
     """Unbiasedness on the GPU: 2 048 spp with the tree vs 2 048 spp with the uniform pick, 48 x 48 pixels."""
     sc = _many_lights_cornell(O, pkg, 48)

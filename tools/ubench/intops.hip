@@ -56,6 +56,16 @@ KERNEL(k_min, "v_min_f32 %0, %0, %1")
 KERNEL(k_lshr, "v_lshrrev_b32 %0, 1, %0")
 KERNEL(k_bfe, "v_bfe_u32 %0, %0, 3, 5")
 KERNEL(k_mac_mix, "v_add_f32 %0, %0, %1\n v_fma_f32 %0, %0, %1, %1")
+// round 3: the instructions of the BVH node step (quantised-plane decode, slab min/max, sort keys) and their candidates
+KERNEL(k_cvt_ub1, "v_cvt_f32_ubyte1 %0, %0")
+KERNEL(k_perm, "v_perm_b32 %0, %0, %1, %1")
+KERNEL(k_min3, "v_min3_f32 %0, %0, %1, %1")
+KERNEL(k_max3, "v_max3_f32 %0, %0, %1, %1")
+KERNEL(k_min_u32, "v_min_u32 %0, %0, %1")
+KERNEL(k_and_or, "v_and_or_b32 %0, %0, %1, %1")
+KERNEL(k_fma_mix, "v_fma_mix_f32 %0, %0, %1, %1 op_sel_hi:[1,0,0]")
+KERNEL(k_cvt_pk_fp8, "v_cvt_f32_fp8 %0, %0")
+KERNEL(k_ldexp, "v_ldexp_f32 %0, %0, %1")
 
 #define KERNEL2(NAME, INSTR)                                                                              \
   __global__ void __launch_bounds__(256) NAME(uint32_t* out, int iters, uint32_t c) {                     \
@@ -124,6 +134,11 @@ int main() {
       {"v_sub_f32", run(k_subf, out, blocks, iters)}, {"v_min_f32", run(k_min, out, blocks, iters)},
       {"v_lshrrev_b32", run(k_lshr, out, blocks, iters)}, {"v_bfe_u32", run(k_bfe, out, blocks, iters)},
       {"add_f32 + fma (2)", run(k_mac_mix, out, blocks, iters)},
+      {"v_cvt_f32_ubyte1", run(k_cvt_ub1, out, blocks, iters)}, {"v_perm_b32", run(k_perm, out, blocks, iters)},
+      {"v_min3_f32", run(k_min3, out, blocks, iters)}, {"v_max3_f32", run(k_max3, out, blocks, iters)},
+      {"v_min_u32", run(k_min_u32, out, blocks, iters)}, {"v_and_or_b32", run(k_and_or, out, blocks, iters)},
+      {"v_fma_mix_f32 (f16 src0)", run(k_fma_mix, out, blocks, iters)}, {"v_cvt_f32_fp8", run(k_cvt_pk_fp8, out, blocks, iters)},
+      {"v_ldexp_f32", run(k_ldexp, out, blocks, iters)},
       {"v_add_f32", run(k_addf, out, blocks, iters)},        {"v_mul_f32", run(k_mulf, out, blocks, iters)},
       {"v_max_f32", run(k_maxf, out, blocks, iters)},        {"v_fmac_f32", run(k_fmac, out, blocks, iters)},
       {"v_fma_f32", run(k_fma, out, blocks, iters)},         {"v_pk_fma_f32", run(k_pk_fma, out, blocks, iters)},
