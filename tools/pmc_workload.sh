@@ -9,7 +9,7 @@ out=$1; tag=$2; shift; shift
 mkdir -p "$out"
 run() { # name, counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$out/$name.log"; exit 1; }
+  rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$out/$name.log"; exit 1; }
   echo "pass $name done"
 }
 BENCH_ARGS=("$@")
