@@ -4,7 +4,7 @@
 //   * dmt-tracer (cli/CLIManager.cpp:11-36): --device|-d cpu|gpu, --scene|-s <file>, --out|-o <path>, --time|-t,
 //       --help|-h.  `--device cpu` is refused: this build has no CPU renderer (the CPU restatement used by the tests is test
 //       infrastructure and is never linked into the product).
-// plus --max-depth <N> (reference constant 32), --gpu-ordinal <N>, --bvh, --light-tree, and --gpus <N>: N contexts, one per GPU
+// plus --max-depth <N> (reference constant 32), --gpu-ordinal <N>, --bvh, --light-tree, --light-tree-reference, and --gpus <N>: N contexts, one per GPU
 // (ordinals 0..N-1), each rendering the interleaved 8x8 tiles j mod N == rank (dmt_set_partition) concurrently; the N
 // films are disjoint and summed on the host (x + 0: an exact gather).  bench.py's N-process RCCL path is the scalable
 // form of the same partition; --gpus is the single-process form for the CLI.
@@ -35,6 +35,7 @@ struct Config {  // defaults: CC/public/cuda-core/host_utils.cuh:25-31
   std::string scenePath;  // --scene <file.json>: the reference's JSON scene description instead of cornellBox()
   bool bvh = false;       // --bvh: traverse the 4-wide BVH instead of testing every triangle
   bool lightTree = false; // --light-tree: importance-driven light choice (csrc/light_tree.hpp) instead of the uniform pick
+  bool lightTreeRef = false; // --light-tree-reference: the reference's tree semantics, up to four lights per bounce (csrc/light_tree_ref.hpp)
   bool widthSet = false, heightSet = false, sppSet = false, depthSet = false;
 
   std::string validate() const {  // host_utils.cuh:35-62
@@ -73,7 +74,8 @@ void printHelp() {
       "                       (PBRT-v4 subset: diffuse materials, triangle meshes, diffuse area lights);\n"
       "                       its resolution, samples and max-depth apply unless given on the command line\n"
       "  --bvh             -- BVH traversal instead of the brute-force triangle loop\n"
-      "  --light-tree      -- pick the NEE light through a light BVH (flux x cosine / distance^2) instead of uniformly");
+      "  --light-tree      -- pick the NEE light through a light BVH (flux x cosine / distance^2) instead of uniformly\n"
+      "  --light-tree-reference -- the reference's light tree semantics: cones, adaptive cuts, up to four lights per bounce");
 }
 
 Config parseArguments(int argc, char** argv) {
@@ -87,6 +89,7 @@ Config parseArguments(int argc, char** argv) {
     else if ((a == "--scene" || a == "-s") && more) c.scenePath = argv[++i];
     else if (a == "--bvh") c.bvh = true;
     else if (a == "--light-tree") c.lightTree = true;
+    else if (a == "--light-tree-reference") c.lightTreeRef = true;
     else if (a == "--kspp" && more) c.kspp = std::atoi(argv[++i]);
     else if (a == "--log-level" && more) c.logLevel = argv[++i];
     else if (a == "--save-partial") c.savePartial = true;
@@ -186,6 +189,7 @@ int main(int argc, char** argv) {
     if (cfg.bvh && dmt_set_accel(ctx, DMT_ACCEL_BVH) != DMT_OK) return fail(ctx, "dmt_set_accel");
     if (dmt_set_partition(ctx, r, cfg.gpus) != DMT_OK) return fail(ctx, "dmt_set_partition");
     if (cfg.lightTree && dmt_set_light_sampling(ctx, DMT_LIGHTS_TREE) != DMT_OK) return fail(ctx, "dmt_set_light_sampling");
+    if (cfg.lightTreeRef && dmt_set_light_sampling(ctx, DMT_LIGHTS_TREE_REFERENCE) != DMT_OK) return fail(ctx, "dmt_set_light_sampling");
   }
   double const uploadMs = msSince(tUpload);
 
