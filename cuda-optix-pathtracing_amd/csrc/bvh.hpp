@@ -268,6 +268,17 @@ inline Result build(float const* xs, float const* ys, float const* zs, uint32_t 
   Result out;
   Builder b;
   b.triBox.resize(n), b.centroid.resize(3 * size_t(n)), b.order.resize(n);
+  // largest |coordinate| of the soup: the slab arithmetic of the traversal (bvh_device.hpp: t = q a + b with b = origin inv +
+  // (-o inv), two separately rounded products) errs by a few ulp of the ORIGIN-SIDE magnitudes, ~1.2e-7 (|o| + |node origin|) in
+  // space, whatever the triangle's own coordinates are -- a triangle near coordinate 0 seen from far away is the case the
+  // per-triangle terms below do not cover (round-2 advisor).  Rays start on the scene's surfaces or at a camera; the padding
+  // allows for origins up to 8x the scene's largest |coordinate| away from the axes' zero.
+  float sceneMaxAbs = 0.f;
+  for (size_t k = 0; k < size_t(n) * 4; ++k) {
+    if ((k & 3) == 3) continue;  // the SoA's pad lane
+    sceneMaxAbs = std::max(sceneMaxAbs, std::max(std::fabs(xs[k]), std::max(std::fabs(ys[k]), std::fabs(zs[k]))));
+  }
+  float const slabPad = 2.5e-7f * 9.f * sceneMaxAbs;
   for (uint32_t i = 0; i < n; ++i) {
     Box bx;
     bx.reset();
@@ -275,11 +286,11 @@ inline Result build(float const* xs, float const* ys, float const* zs, uint32_t 
       float const p[3] = {xs[4 * size_t(i) + v], ys[4 * size_t(i) + v], zs[4 * size_t(i) + v]};
       bx.grow(p);
     }
-    // padding: far above the rounding of the triangle and slab tests (~1e-7 relative), far below
-    // anything that costs traversal work
+    // padding: far above the rounding of the triangle test (~1e-7 relative to the triangle) and of the slab tests (slabPad),
+    // far below anything that costs traversal work
     for (int a = 0; a < 3; ++a) {
       float const m = std::max(std::fabs(bx.lo[a]), std::fabs(bx.hi[a]));
-      float const pad = 1e-5f * (bx.hi[a] - bx.lo[a]) + 4e-6f * m + 1e-7f;
+      float const pad = 1e-5f * (bx.hi[a] - bx.lo[a]) + 4e-6f * m + 1e-7f + slabPad;
       bx.lo[a] -= pad, bx.hi[a] += pad;
     }
     b.triBox[i] = bx;

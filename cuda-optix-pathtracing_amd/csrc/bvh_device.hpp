@@ -100,10 +100,13 @@ struct TraversalCounters {  // per-lane work counters (stats build of the kernel
 // Slab setup: a child's plane at quantised coordinate q is at  origin + q * scale, so its ray parameter is
 //   t = (origin + q * scale - o) * inv = q * (scale * inv) + (origin * inv + oi),   oi = -o * inv,
 // i.e. one FMA per plane after three multiplies and three FMAs per node.  The near / far plane of each axis is picked
-// by the sign of the direction.  Everything here only has to stay CONSERVATIVE: the evaluation errs by a few ulp of
-// |origin - o| * |inv|, i.e. ~3e-7 of the coordinates in space, more than ten times below the builder's box padding
-// (4e-6 * |coordinate| + 1e-5 * extent); a zero direction component gives inf * 0 or inf - inf = NaN on that axis,
-// which max/min drop, i.e. the axis is ignored.  Hits are decided by the triangle test alone.
+// by the sign of the direction.  Everything here only has to stay CONSERVATIVE.  b adds two separately rounded products
+// (origin * inv by the FMA, -o * inv before it), so t errs by a few ulp of |o * inv| + |origin * inv| -- in space ~1.2e-7 of
+// the ray origin's and the node origin's COORDINATE MAGNITUDES, not of their difference and not of the triangle's own
+// coordinates.  The builder therefore pads every triangle box by 2.25e-6 x the soup's largest |coordinate| on top of its
+// per-triangle terms (bvh.hpp: slabPad; covers ray origins up to 8x that far out), which costs no instruction here;
+// subtracting first ((origin - o) * inv) would cost three.  A zero direction component gives inf * 0 or inf - inf = NaN on
+// that axis, which max/min drop, i.e. the axis is ignored.  Hits are decided by the triangle test alone.
 struct SlabRay2 {
   f3 inv, oi;
   bool negx, negy, negz;

@@ -1693,6 +1693,7 @@ struct dmt_ctx {
   uint32_t lightTreeNodes = 0;
   int lightTreeDepth = 0;
   bool lightTreeValid = false;
+  bool lightTreeTooDeep = false;   // the last build exceeded the walk's depth guard: the uniform pick is used instead (dmt_last_error says so)
   bool lightsTreeable = false;     // every record of the light list is a point or spot light
   std::vector<std::pair<void const*, int>> occupancy;  // megakernel variant -> resident 256-thread blocks per CU
   // SURVEY 8f-1 image textures (one allocation each)
@@ -1850,10 +1851,10 @@ SamplerParams computeSamplerParams(int width, int height) {
 
 // the light tree applies to plain point / spot light lists; textured or emissive-triangle scenes keep the uniform pick
 bool useLightTreeRef(dmt_ctx const* c) {
-  return c->lightSampling == DMT_LIGHTS_TREE_REFERENCE && c->lightCount > 1 && c->lightsTreeable && c->areaCount == 0 && c->texCount == 0 && !c->hasBlend;
+  return !c->lightTreeTooDeep && c->lightSampling == DMT_LIGHTS_TREE_REFERENCE && c->lightCount > 1 && c->lightsTreeable && c->areaCount == 0 && c->texCount == 0 && !c->hasBlend;
 }
 bool useLightTree(dmt_ctx const* c) {
-  return c->lightSampling == DMT_LIGHTS_TREE && c->lightCount > 1 && c->lightsTreeable && c->areaCount == 0 && c->texCount == 0 && !c->hasBlend;
+  return !c->lightTreeTooDeep && c->lightSampling == DMT_LIGHTS_TREE && c->lightCount > 1 && c->lightsTreeable && c->areaCount == 0 && c->texCount == 0 && !c->hasBlend;
 }
 int ensureLightTree(dmt_ctx* ctx);
 
@@ -2006,7 +2007,10 @@ int ensureLightTree(dmt_ctx* ctx) {
     bool ok = true;
     std::vector<LightTreeRefNode> const nodes = buildLightTreeRef(ctx->h_lights.data(), ctx->lightCount, &ctx->lightTreeDepth, &ok);
     if (!ok) return fail(ctx, DMT_ERR_STATE, "light tree: only point and spot lights can be in the light list");
-    if (ctx->lightTreeDepth > kLightTreeRefMaxDepth) return fail(ctx, DMT_ERR_STATE, "light tree too deep");
+    if (ctx->lightTreeDepth > kLightTreeRefMaxDepth) {
+      ctx->lightTreeTooDeep = true;
+      return DMT_OK;
+    }
     int const rcR = devAlloc(ctx, &ctx->d_lightTreeRef, nodes.size());
     if (rcR) return rcR;
     if (!nodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_lightTreeRef, nodes.data(), nodes.size() * sizeof(LightTreeRefNode), hipMemcpyHostToDevice));
@@ -2022,7 +2026,10 @@ int ensureLightTree(dmt_ctx* ctx) {
     items.push_back(it);
   }
   std::vector<LightTreeNode> const nodes = light_tree::build(items, &ctx->lightTreeDepth);
-  if (ctx->lightTreeDepth > 60) return fail(ctx, DMT_ERR_STATE, "light tree too deep");
+  if (ctx->lightTreeDepth > 60) {  // lights at geometrically growing spacing: the walk's guard would cut paths short -> uniform pick
+    ctx->lightTreeTooDeep = true;
+    return DMT_OK;
+  }
   int const rc = devAlloc(ctx, &ctx->d_lightTree, nodes.size());
   if (rc) return rc;
   if (!nodes.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_lightTree, nodes.data(), nodes.size() * sizeof(LightTreeNode), hipMemcpyHostToDevice));
@@ -2270,6 +2277,7 @@ int dmt_upload_lights(dmt_ctx* ctx, const void* lights32, uint32_t count, const 
   ctx->haveLights = true;
   ctx->h_lights.assign(static_cast<uint8_t const*>(lights32), static_cast<uint8_t const*>(lights32) + size_t(count) * 32);
   ctx->lightTreeValid = false;
+  ctx->lightTreeTooDeep = false;
   ctx->lightsTreeable = count > 0;
   for (uint32_t i = 0; i < count; ++i) {  // a directional light in the list (PBRT "distant") has no position: such lists keep the uniform pick
     uint16_t type;
@@ -2332,7 +2340,7 @@ int dmt_set_light_sampling(dmt_ctx* ctx, int mode) {
   if (!ctx) return DMT_ERR_INVALID;
   if (mode != DMT_LIGHTS_UNIFORM && mode != DMT_LIGHTS_TREE && mode != DMT_LIGHTS_TREE_REFERENCE)
     return fail(ctx, DMT_ERR_INVALID, "dmt_set_light_sampling: unknown mode");
-  if (mode != ctx->lightSampling) ctx->lightTreeValid = false;  // the two trees are different structures
+  if (mode != ctx->lightSampling) ctx->lightTreeValid = false, ctx->lightTreeTooDeep = false;  // the two trees are different structures
   ctx->lightSampling = mode;
   return DMT_OK;
 }
@@ -2560,6 +2568,14 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   if (y1 > ctx->filmH) y1 = ctx->filmH;
   if (spp == 0 || x1 <= x0 || y1 <= y0) return DMT_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // the light tree is built before anything asks which kernel will run: a tree deeper than the walk's guard switches the
+  // context back to the uniform pick (lightTreeTooDeep), which changes the kernel, its occupancy and the launch shape
+  if ((useLightTree(ctx) || useLightTreeRef(ctx)) && !ctx->lightTreeValid) {
+    if (int const rcT = ensureLightTree(ctx)) return rcT;
+  }
+  if (stats6 && (ctx->texCount > 0 || ctx->hasBlend || ctx->areaCount > 0 || useLightTree(ctx) || useLightTreeRef(ctx)))
+    return fail(ctx, DMT_ERR_STATE, "dmt_render_stats / dmt_render_profile: the counting kernels exist for the plain and env-map BVH kernels only; "
+                                    "with textures, blended materials, emissive triangles or a light tree they would describe a different kernel");
 
   RenderParams P{};
   P.scene = sceneView(ctx);

@@ -53,7 +53,9 @@ DMT_LT_HD float lt_importance(LightTreeNode const& nd, float px, float py, float
   float const halfDiag = 0.5f * sqrtf(dx * dx + dy * dy + dz * dz);
   float wx = px - cx, wy = py - cy, wz = pz - cz;
   float const d2 = wx * wx + wy * wy + wz * wz;
-  float const distSqr = fmaxf(d2, halfDiag);  // :112-113 (distance squared against a length, as written)
+  // :112-113 (distance squared against a length, as written); the floor keeps a zero-radius light AT the shading point from
+  // producing inf importance -> NaN probabilities (round-2 advisor)
+  float const distSqr = fmaxf(fmaxf(d2, halfDiag), 1e-20f);
   // sine / cosine of the angle the cluster's bounding sphere subtends (:84-96)
   float sinB = 0.f, cosB = -1.f;  // inside the sphere: the cluster fills the hemisphere
   if (d2 >= halfDiag * halfDiag && d2 > 0.f) {

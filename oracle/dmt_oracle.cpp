@@ -1675,7 +1675,7 @@ inline float ltImportance(LtNode const& nd, V3 p, V3 n) {
   float const halfDiag = 0.5f * sqrtf(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z);
   V3 const w = p - c;
   float const d2 = w.x * w.x + w.y * w.y + w.z * w.z;
-  float const distSqr = fmaxf(d2, halfDiag);
+  float const distSqr = fmaxf(fmaxf(d2, halfDiag), 1e-20f);  // floor: a zero-radius light at the shading point (as the product)
   float sinB = 0.f, cosB = -1.f;
   if (d2 >= halfDiag * halfDiag && d2 > 0.f) {
     float const s2 = (halfDiag * halfDiag) / d2;

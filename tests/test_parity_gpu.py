@@ -959,6 +959,52 @@ def test_textured_metallic_vs_oracle(renderer, pkg, O, tmp_path):
     assert float((rel > 1e-2).mean()) < 1e-2, float((rel > 1e-2).mean())
 
 
+def test_oren_nayar_albedo_texture_in_a_reference_format_scene(renderer, pkg, O, tmp_path):
+    """Round-2 advisor: the albedo path of apply_material_textures was only covered by a hand-built scene.  Here a JSON scene in
+    the reference's schema -- three_boxes.json with the chalk floor's `diffuse` replaced by the reference's chipped-paint
+    albedo PNG (a data fixture) on an `oren-nayar-dielectric` material -- goes through the loader, the *_tex kernels and the
+    oracle; the texture must change the floor."""
+    import json, shutil
+    src = GOLDEN / "json_scene"
+    shutil.copy(src / "sky_32x16.png", tmp_path / "sky_32x16.png")
+    shutil.copy(GOLDEN / "scene_test" / "res" / "textures" / "chippedPaint" / "Paint_Chipped_1K_albedo.png", tmp_path / "albedo.png")
+    films = {}
+    for tag in ("textured", "plain"):
+        d = json.loads((src / "three_boxes.json").read_text())
+        if tag == "textured":
+            d["textures"] = [{"name": "paint", "type": "diffuse", "path": "./albedo.png"}]
+            chalk = [m for m in d["materials"] if "oren-nayar-dielectric" in m][0]
+            chalk["diffuse"] = "paint"
+        (tmp_path / f"{tag}.json").write_text(json.dumps(d))
+        hs = pkg.host_scene.load_json(tmp_path / f"{tag}.json")
+        osc = O.Scene(hs.xs, hs.ys, hs.zs, hs.mat_id, hs.bsdfs, hs.lights, hs.inf_lights, hs.camera)
+        osc.set_envmap(hs.env_rgb)
+        if tag == "textured":
+            assert hs.tex_desc is not None and hs.mat_tex[:, 0].tolist().count(0) == 1
+            osc.set_textures(hs.tex_rgba, hs.tex_desc, hs.mat_tex, hs.tri_uv)
+        renderer.upload_scene(hs)
+        renderer.set_limits(hs.max_depth)
+        renderer.set_accel(1)
+        renderer.set_partition(0, 1)
+        try:
+            renderer.film_clear()
+            renderer.render(16)
+            renderer.sync()
+            mean, m2 = renderer.download_film()
+            if tag == "textured":
+                with pytest.raises(pkg.DmtError, match="counting kernels"):      # the stats build has no texture variant: refused, not mislabelled
+                    renderer.render_stats(1)
+        finally:
+            renderer.set_accel(0)
+            renderer.clear_envmap()
+            renderer.upload_textures(None, None, None, None)
+        om, om2 = O.render(osc, 16, max_depth=hs.max_depth, threads=8)[:2]
+        assert np.array_equal(m2[..., 3], om2[..., 3])
+        assert float(np.sqrt(np.mean((mean[..., :3] - om[..., :3]) ** 2))) < 1e-3 * max(1.0, float(om[..., :3].mean()))
+        films[tag] = mean
+    assert film_rmse(films["textured"], films["plain"]) > 5e-3
+
+
 def test_cli_renders_a_json_scene(tmp_path):
     import subprocess
     from pathlib import Path
