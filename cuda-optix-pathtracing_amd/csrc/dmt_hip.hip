@@ -1134,7 +1134,7 @@ DMT_DEV void item_complete(KArgs Pk, uint32_t gtid, int lane, uint32_t seq, Wave
 // where work items are fetched (item_fetch is large, and the kernel already fills most of the instruction cache): a wave
 // starts with no item, and a wave whose last live item was retired comes here because all its lanes are starving.
 DMT_DEV void sched_draw(KArgs Pk, uint32_t gtid, int lane, WaveSched& W, LaneSched& Ls, bool want) {
-  if (W.nextUnit == W.totalUnits) {  // the item units are drawn from is used up (or there is none yet): fetch the next if there is room
+  if (__builtin_expect(W.nextUnit == W.totalUnits, 0)) {  // the item units are drawn from is used up (or there is none yet): fetch the next if there is room
     if (!W.exhausted && W.fetched - W.cur < 2u && W.slabFree != 0u) {
       uint32_t units = 0;
       if (item_fetch(Pk, gtid, lane, W.fetched, W, units)) W.alloc = W.fetched, ++W.fetched, W.nextUnit = 0, W.totalUnits = units;
@@ -1599,8 +1599,10 @@ __global__ void k_test_bsdf(Rec32 rec, int n, float const* ns3, float const* wo3
   Bsdf const b = bsdf_prepare(rec, ns, wo);
   float* p = prep12 + 12 * size_t(i);
   p[0] = b.weight.x, p[1] = b.weight.y, p[2] = b.weight.z;
-  p[3] = b.ms.x, p[4] = b.ms.y, p[5] = b.ms.z;
-  p[6] = b.escale, p[7] = float(b.type), p[8] = b.ax, p[9] = b.ay, p[10] = b.phi0, p[11] = b.eta;
+  bool const oren = b.type == BS_OREN, ggx = b.type == BS_GGX_DIEL || b.type == BS_GGX_COND;  // the two kinds share registers (Bsdf)
+  p[3] = oren ? b.ms.x : 0.f, p[4] = oren ? b.ms.y : 0.f, p[5] = oren ? b.ms.z : 0.f;
+  p[6] = ggx ? b.escale : 0.f, p[7] = float(b.type), p[8] = ggx ? b.ax : 0.f, p[9] = ggx ? b.ay : 0.f, p[10] = ggx ? b.phi0 : 0.f;
+  p[11] = b.type == BS_GGX_DIEL ? b.eta : 0.f;
   BsdfSample const s = sample_bsdf(b, wo, ns, ns, mk2(u2[2 * i], u2[2 * i + 1]), uc[i]);
   float* o = samp10 + 10 * size_t(i);
   o[0] = s.wi.x, o[1] = s.wi.y, o[2] = s.wi.z, o[3] = s.f.x, o[4] = s.f.y, o[5] = s.f.z;

@@ -907,12 +907,19 @@ DMT_DEV float table_read_2d(float const* table, float x, float y, int sx, int sy
 struct Bsdf {  // decoded + prepared, registers only
   uint32_t type;
   f3 weight;
-  // Oren-Nayar: a, b, ms.   GGX: escale, ax, ay, phi0, iso, and {eta, rt, tt} or {eta3, kappa3}
-  float a, b;
-  f3 ms;
-  float escale, ax, ay, phi0;
+  // A lane's material is ONE kind, so the Oren-Nayar terms and the GGX terms share five registers (both kernels sit at their
+  // VGPR budget; every register not kept live across the shading step is one less reload from scratch inside it).
+  // Oren-Nayar: a, b, ms.   GGX: escale, ax, ay, phi0, eta, iso, and {rt, tt} or {eta3, kappa3}
+  union {
+    struct {
+      float a, b;
+      f3 ms;
+    };
+    struct {
+      float escale, ax, ay, phi0, eta;
+    };
+  };
   bool iso;
-  float eta;
   f3 c0, c1;  // dielectric: reflectanceTint, transmittanceTint; conductor: eta, kappa
 };
 

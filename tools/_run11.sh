@@ -1,0 +1,7 @@
+mkdir -p gpurun_out/r3
+V=$PWD/cuda-optix-pathtracing_amd/csrc/variants
+for lib in cur r02head; do
+  if [ $lib = cur ]; then unset DMT_HIP_LIB; else export DMT_HIP_LIB=$V/libdmt_hip_$lib.so; fi
+  timeout -k 10 300 python bench.py --no-cpu-baseline --no-secondary --steps 10 > gpurun_out/r3/ab4_c2_${lib}.log 2>&1; echo "c2 $lib rc=$? $(grep -ao '"value": [0-9.]*' gpurun_out/r3/ab4_c2_${lib}.log | head -1)"
+  timeout -k 10 300 python bench.py --no-cpu-baseline --workload random1M_1024x1024_512spp_8bounces --steps 3 --warmup 1 > gpurun_out/r3/ab4_c4_${lib}.log 2>&1; echo "c4 $lib rc=$? $(grep -ao '"value": [0-9.]*' gpurun_out/r3/ab4_c4_${lib}.log | head -1) $(grep -ao '"node_visits": [0-9.]*' gpurun_out/r3/ab4_c4_${lib}.log | head -1)"
+done
