@@ -306,6 +306,9 @@ def main():
     ap.add_argument("--kspp", type=int, default=0, help="samples per pixel per kernel launch (0 = all spp in one launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the BASELINE config 4 record appended to the default run")
+    ap.add_argument("--cornell-bvh", action="store_true",
+                    help="experiment (VERDICT r2 item 9): run a Cornell workload through the BVH kernel instead of the brute-force loop "
+                         "(films are bit-identical); the roofline record then still describes the brute-force model")
     ap.add_argument("--cpu-band-rows", type=int, default=16)
     args = ap.parse_args()
 
@@ -349,7 +352,7 @@ def main():
     r.set_stream(stream.cuda_stream)
     r.upload_scene(scene)
     r.set_limits(max_depth)
-    if use_bvh:
+    if use_bvh or args.cornell_bvh:
         r.set_accel(1)
     r.set_partition(rank, world)
     film = torch.zeros((2, height, width, 4), dtype=torch.float32, device=dev)  # one allocation: one reduce per step
@@ -525,7 +528,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene": scene_text,
                        "width": width, "height": height, "spp": spp, "max_depth": max_depth, "kspp": kspp,
-                       "accel": "bvh4" if use_bvh else "brute_force", "partition": f"interleaved 8x8 tiles over {world} GPU(s)",
+                       "accel": "bvh4" if (use_bvh or args.cornell_bvh) else "brute_force", "partition": f"interleaved 8x8 tiles over {world} GPU(s)",
                        "combine": ("none" if world == 1 else
                                    "gather of owned 8x8 tiles on rank 0 (grouped send/recv; DMT_COMBINE=gather)"
                                    if os.environ.get("DMT_COMBINE", "reduce") == "gather" else
