@@ -49,6 +49,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL and CUDA-tensor sharing fail with the legacy mode); the driver's
+# environment exports it already -- this only covers a shell that does not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 HBM_MEASURED_GBS = 6290.0      # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy); this box: copy 4.7, triad 5.9, fill 6.8
