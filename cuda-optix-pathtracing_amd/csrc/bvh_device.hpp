@@ -119,22 +119,22 @@ DMT_DEV SlabRay2 slab_ray2(f3 o, f3 d) {
   return r;
 }
 enum : int { TR_IDLE = 0, TR_CLOSEST = 1, TR_SHADOW = 2, TR_DONE = 3 };
+// The ray itself (origin, direction) is NOT part of the state: the caller holds it anyway and hands it to the leaf step
+// (six registers per lane less in the megakernel, where every register of the traversal is live through shading).
 struct Traversal {
   int phase;
   bool doC, doS;     // what this round of the lane consists of
   uint32_t cur;
   BvhStack stack;
-  f3 o, d;           // ray of the current phase
-  SlabRay2 sr;
-  float tmax;        // closest: best t so far; shadow: light distance
-  int bestTri;       // ORIGINAL index
-  uint32_t bestOrig;
-  float bt, bu, bv;
+  SlabRay2 sr;       // slab form of the ray of the current phase
+  float tlim;        // closest: t of the best hit so far (kInf: none); shadow: the light's distance
+  int bestTri;       // closest: ORIGINAL index of the best hit, -1 = none
+  float bu, bv;
   bool occluded;
 };
-DMT_DEV void trav_set_ray(Traversal& tv, f3 o, f3 d) {
-  tv.o = o, tv.d = d;
+DMT_DEV void trav_set_ray(Traversal& tv, f3 o, f3 d, float tlim) {
   tv.sr = slab_ray2(o, d);
+  tv.tlim = tlim;
   tv.cur = 0u;
   tv.stack.sp = 0;
 }
@@ -169,7 +169,7 @@ DMT_DEV void kswap(uint32_t& a, uint32_t& b) {
 // node step: cur is an inner node
 template <bool STATS = false>
 DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
-  float const tlimit = tv.phase == TR_CLOSEST ? tv.bt : tv.tmax;
+  float const tlimit = tv.tlim;
   uint4 const* const nb = reinterpret_cast<uint4 const*>(bv.nodes + tv.cur);
   if constexpr (STATS) ++tc->nodes;
   uint4 const w0 = nb[0];  // ox oy oz meta
@@ -226,35 +226,35 @@ DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc =
     tv.cur = p0 ? r0 : tv.stack.pop(bv);
   }
 }
-// leaf test: `ref` is a leaf reference (one triangle pair); updates the best hit / the occlusion flag only
+// leaf test: `ref` is a leaf reference (one triangle pair) of the ray (o, d); updates the best hit / the occlusion flag only
 template <bool STATS = false>
-DMT_DEV void trav_leaf_ref(BvhView const& bv, Traversal& tv, uint32_t ref, TraversalCounters* tc = nullptr) {
-  PairHit const h = pair_test(bv.pairs + (ref & ~kBvhLeafFlag), tv.o, tv.d);
+DMT_DEV void trav_leaf_ref(BvhView const& bv, Traversal& tv, f3 o, f3 d, uint32_t ref, TraversalCounters* tc = nullptr) {
+  PairHit const h = pair_test(bv.pairs + (ref & ~kBvhLeafFlag), o, d);
   if constexpr (STATS) tc->tris += h.orig0 != h.orig1 ? 2u : 1u;  // a one-triangle leaf repeats its triangle
-  if (tv.phase == TR_CLOSEST) {  // brute force keeps the lowest index among equal t (strict < in index order)
-    if (h.valid0 && (h.t.x < tv.bt || (h.t.x == tv.bt && h.orig0 < tv.bestOrig)))
-      tv.bt = h.t.x, tv.bu = h.u.x, tv.bv = h.v.x, tv.bestOrig = h.orig0, tv.bestTri = int(h.orig0);
-    if (h.valid1 && (h.t.y < tv.bt || (h.t.y == tv.bt && h.orig1 < tv.bestOrig)))
-      tv.bt = h.t.y, tv.bu = h.u.y, tv.bv = h.v.y, tv.bestOrig = h.orig1, tv.bestTri = int(h.orig1);
-  } else if ((h.valid0 && h.t.x < tv.tmax) || (h.valid1 && h.t.y < tv.tmax)) {
+  if (tv.phase == TR_CLOSEST) {  // brute force keeps the lowest index among equal t (strict < in index order; -1 = none is the largest)
+    if (h.valid0 && (h.t.x < tv.tlim || (h.t.x == tv.tlim && h.orig0 < uint32_t(tv.bestTri))))
+      tv.tlim = h.t.x, tv.bu = h.u.x, tv.bv = h.v.x, tv.bestTri = int(h.orig0);
+    if (h.valid1 && (h.t.y < tv.tlim || (h.t.y == tv.tlim && h.orig1 < uint32_t(tv.bestTri))))
+      tv.tlim = h.t.y, tv.bu = h.u.y, tv.bv = h.v.y, tv.bestTri = int(h.orig1);
+  } else if ((h.valid0 && h.t.x < tv.tlim) || (h.valid1 && h.t.y < tv.tlim)) {
     tv.occluded = true;
   }
 }
 // leaf step of the synchronous traversal: cur is a leaf reference
 template <bool STATS = false>
-DMT_DEV void trav_leaf(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
-  trav_leaf_ref<STATS>(bv, tv, tv.cur, tc);
+DMT_DEV void trav_leaf(BvhView const& bv, Traversal& tv, f3 o, f3 d, TraversalCounters* tc = nullptr) {
+  trav_leaf_ref<STATS>(bv, tv, o, d, tv.cur, tc);
   tv.cur = (tv.phase != TR_CLOSEST && tv.occluded) ? kBvhEmpty : tv.stack.pop(bv);
 }
 // ---- whole traversals of one ray per lane (test kernels, lane_step<BVH>): the same step functions in a loop ----
 template <bool STATS>
-DMT_DEV void trav_run(BvhView const& bv, Traversal& tv, TraversalCounters* tc) {
+DMT_DEV void trav_run(BvhView const& bv, Traversal& tv, f3 o, f3 d, TraversalCounters* tc) {
   for (;;) {
     bool const live = tv.cur != kBvhEmpty;
     if (!__any(live)) break;
     bool const onLeaf = live && (tv.cur & kBvhLeafFlag) != 0u;
     if (live && !onLeaf) trav_node<STATS>(bv, tv, tc);
-    if (onLeaf) trav_leaf<STATS>(bv, tv, tc);
+    if (onLeaf) trav_leaf<STATS>(bv, tv, o, d, tc);
   }
 }
 // closest hit: bestTri = ORIGINAL triangle index or -1
@@ -264,11 +264,11 @@ DMT_DEV void bvh_closest(BvhView const& bv, bool active, f3 o, f3 d, uint32_t gt
   Traversal tv{};
   if constexpr (STATS) tv.stack.ovfCount = &tc->overflowPushes;
   tv.phase = TR_CLOSEST;
-  tv.bt = kInf, tv.bestTri = -1, tv.bestOrig = 0xFFFFFFFFu, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false, tv.tmax = kInf;
-  trav_set_ray(tv, o, d);
+  tv.bestTri = -1, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false;
+  trav_set_ray(tv, o, d, kInf);
   if (!active) tv.cur = kBvhEmpty;
-  trav_run<STATS>(bv, tv, tc);
-  bestTri = tv.bestTri, bt = tv.bt, bu = tv.bu, bvv = tv.bv;
+  trav_run<STATS>(bv, tv, o, d, tc);
+  bestTri = tv.bestTri, bt = tv.tlim, bu = tv.bu, bvv = tv.bv;
 }
 // any hit with t < tmax
 template <bool STATS = false>
@@ -277,10 +277,10 @@ DMT_DEV bool bvh_any(BvhView const& bv, bool active, f3 o, f3 d, float tmax, uin
   Traversal tv{};
   if constexpr (STATS) tv.stack.ovfCount = &tc->overflowPushes;
   tv.phase = TR_SHADOW;
-  tv.bt = kInf, tv.bestTri = -1, tv.bestOrig = 0xFFFFFFFFu, tv.occluded = false, tv.tmax = tmax;
-  trav_set_ray(tv, o, d);
+  tv.bestTri = -1, tv.occluded = false;
+  trav_set_ray(tv, o, d, tmax);
   if (!active) tv.cur = kBvhEmpty;
-  trav_run<STATS>(bv, tv, tc);
+  trav_run<STATS>(bv, tv, o, d, tc);
   return tv.occluded;
 }
 

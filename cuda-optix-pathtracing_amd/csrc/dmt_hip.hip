@@ -174,6 +174,11 @@ DMT_DEV f3 get_Lfin() {
 DMT_DEV void put_finIdx(uint32_t i) { s_cold[6 * kLdsThreads + threadIdx.x] = __uint_as_float(i); }
 DMT_DEV uint32_t get_finIdx() { return __float_as_uint(s_cold[6 * kLdsThreads + threadIdx.x]); }
 DMT_DEV f3 ray_dir(PathState const& st) { return mk3(st.rp.dx.x, st.rp.dy.x, st.rp.dz.x); }
+DMT_DEV f3 ray_org(PathState const& st) { return mk3(st.rp.ox.x, st.rp.oy.x, st.rp.oz.x); }
+DMT_DEV void swap_rays(PathState& st) {  // path ray <-> pending shadow ray (megakernel_body_bvh)
+  auto sw = [](v2f& p) { float const t = p.x; p.x = p.y, p.y = t; };
+  sw(st.rp.ox), sw(st.rp.oy), sw(st.rp.oz), sw(st.rp.dx), sw(st.rp.dy), sw(st.rp.dz);
+}
 DMT_DEV void set_ray(PathState& st, f3 o, f3 d) {
   st.rp.ox.x = o.x, st.rp.oy.x = o.y, st.rp.oz.x = o.z;
   st.rp.dx.x = d.x, st.rp.dy.x = d.y, st.rp.dz.x = d.z;
@@ -1303,18 +1308,19 @@ DMT_DEV void megakernel_body_bvh() {
         Ls.prepared = false;
         if constexpr (STATS) ++ls.samples;
       }
-      // B. start a round: closest-hit ray and/or pending shadow ray
+      // B. start a round: pending shadow ray first, then the closest-hit ray.  The ray being traversed is ALWAYS st.rp's
+      //    .x half (the traversal keeps no copy of it): a round with a shadow ray swaps the halves, and swaps them back when
+      //    the shadow ray is done, so that the closest-hit ray is in .x again when the lane shades.
       if (idle && (st.active || st.hasShadow)) {
         tv.doC = st.active, tv.doS = st.hasShadow;
-        tv.bt = kInf, tv.bestTri = -1, tv.bestOrig = 0xFFFFFFFFu, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false;
-        tv.tmax = st.smax;
-        if (tv.doC) {
-          tv.phase = TR_CLOSEST;
-          trav_set_ray(tv, mk3(st.rp.ox.x, st.rp.oy.x, st.rp.oz.x), mk3(st.rp.dx.x, st.rp.dy.x, st.rp.dz.x));
-        } else {
+        tv.bestTri = -1, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false;
+        if (tv.doS) {
           tv.phase = TR_SHADOW;
-          trav_set_ray(tv, mk3(st.rp.ox.y, st.rp.oy.y, st.rp.oz.y), mk3(st.rp.dx.y, st.rp.dy.y, st.rp.dz.y));
+          swap_rays(st);
+        } else {
+          tv.phase = TR_CLOSEST;
         }
+        trav_set_ray(tv, ray_org(st), ray_dir(st), tv.doS ? st.smax : kInf);
         if constexpr (STATS) ls.closest += tv.doC ? 1u : 0u, ls.shadow += tv.doS ? 1u : 0u;
       }
       // R. item cur has no units left: is it complete?
@@ -1333,9 +1339,10 @@ DMT_DEV void megakernel_body_bvh() {
       for (;;) {
         bool traversing = tv.phase == TR_CLOSEST || tv.phase == TR_SHADOW;
         if (traversing && tv.cur == kBvhEmpty) {  // ray finished: next ray of the round, or done
-          if (tv.phase == TR_CLOSEST && tv.doS) {
-            tv.phase = TR_SHADOW;
-            trav_set_ray(tv, mk3(st.rp.ox.y, st.rp.oy.y, st.rp.oz.y), mk3(st.rp.dx.y, st.rp.dy.y, st.rp.dz.y));
+          if (tv.phase == TR_SHADOW) swap_rays(st);  // .x = the closest-hit ray again
+          if (tv.phase == TR_SHADOW && tv.doC) {
+            tv.phase = TR_CLOSEST;
+            trav_set_ray(tv, ray_org(st), ray_dir(st), kInf);
           } else {
             tv.phase = TR_DONE;
             traversing = false;
@@ -1351,14 +1358,14 @@ DMT_DEV void megakernel_body_bvh() {
 #ifdef DMT_BVH_BOTH_STEPS  // experiment: every traversing lane advances every iteration (node and leaf code both run)
         if constexpr (STATS) ++ls.itNode, ++ls.itLeaf, ls.lanesLeaf += onLeaf ? 1u : 0u;
         if (onNode) trav_node<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
-        if (onLeaf) trav_leaf<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
+        if (onLeaf) trav_leaf<STATS>(bvh, tv, ray_org(st), ray_dir(st), STATS ? &ls.tc : nullptr);
 #else
         if (nNode * DMT_BVH_NODE_WEIGHT >= nLeaf * DMT_BVH_LEAF_WEIGHT) {
           if constexpr (STATS) ++ls.itNode;
           if (onNode) trav_node<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
         } else {
           if constexpr (STATS) ++ls.itLeaf, ls.lanesLeaf += onLeaf ? 1u : 0u;
-          if (onLeaf) trav_leaf<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
+          if (onLeaf) trav_leaf<STATS>(bvh, tv, ray_org(st), ray_dir(st), STATS ? &ls.tc : nullptr);
         }
 #endif
       }

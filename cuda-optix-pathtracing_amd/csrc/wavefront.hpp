@@ -133,6 +133,7 @@ DMT_DEV void wf_trace_body(WfParams const& W) {
   tv.phase = TR_IDLE;
   tv.cur = kBvhEmpty;
   uint32_t path = 0;
+  f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);  // the ray this lane is tracing
   // The wave draws CHUNKS of the queue with one atomic each and hands their entries to its lanes as they fall idle: one
   // shared cursor word saturates near 90 dequeues per microsecond on this chip (MI355X_MICROARCH.md, price list
   // "dequeue"), which a per-refill atomic reaches at ~1.4 G rays/s.
@@ -140,9 +141,9 @@ DMT_DEV void wf_trace_body(WfParams const& W) {
   bool exhausted = false;                // the cursor has passed the end of the queue
   auto start_shadow = [&]() {
     tv.phase = TR_SHADOW;
-    tv.tmax = wf_plane(W, WF_SMAX)[path];
-    trav_set_ray(tv, mk3(wf_plane(W, WF_SOX)[path], wf_plane(W, WF_SOY)[path], wf_plane(W, WF_SOZ)[path]),
-                 mk3(wf_plane(W, WF_SDX)[path], wf_plane(W, WF_SDY)[path], wf_plane(W, WF_SDZ)[path]));
+    ro = mk3(wf_plane(W, WF_SOX)[path], wf_plane(W, WF_SOY)[path], wf_plane(W, WF_SOZ)[path]);
+    rd = mk3(wf_plane(W, WF_SDX)[path], wf_plane(W, WF_SDY)[path], wf_plane(W, WF_SDZ)[path]);
+    trav_set_ray(tv, ro, rd, wf_plane(W, WF_SMAX)[path]);
     if constexpr (STATS) ++ls.shadow;
   };
   for (;;) {
@@ -190,11 +191,12 @@ DMT_DEV void wf_trace_body(WfParams const& W) {
           path = queue[my];
           uint32_t const f = flagsPlane[path];
           tv.doC = (f & kWfActive) != 0u, tv.doS = (f & kWfShadow) != 0u;
-          tv.bt = kInf, tv.bestTri = -1, tv.bestOrig = 0xFFFFFFFFu, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false;
+          tv.bestTri = -1, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false;
           if (tv.doC) {
             tv.phase = TR_CLOSEST;
-            trav_set_ray(tv, mk3(wf_plane(W, WF_OX)[path], wf_plane(W, WF_OY)[path], wf_plane(W, WF_OZ)[path]),
-                         mk3(wf_plane(W, WF_DX)[path], wf_plane(W, WF_DY)[path], wf_plane(W, WF_DZ)[path]));
+            ro = mk3(wf_plane(W, WF_OX)[path], wf_plane(W, WF_OY)[path], wf_plane(W, WF_OZ)[path]);
+            rd = mk3(wf_plane(W, WF_DX)[path], wf_plane(W, WF_DY)[path], wf_plane(W, WF_DZ)[path]);
+            trav_set_ray(tv, ro, rd, kInf);
             if constexpr (STATS) ++ls.closest;
           } else if (tv.doS) {
             start_shadow();
@@ -212,7 +214,7 @@ DMT_DEV void wf_trace_body(WfParams const& W) {
       if (onNode) trav_node<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
     } else {
       if constexpr (STATS) ++ls.itLeaf, ls.lanesLeaf += onLeaf ? 1u : 0u;
-      if (onLeaf) trav_leaf<STATS>(bvh, tv, STATS ? &ls.tc : nullptr);
+      if (onLeaf) trav_leaf<STATS>(bvh, tv, ro, rd, STATS ? &ls.tc : nullptr);
     }
   }
   flush_stats<STATS>(Pk, ls);
