@@ -59,6 +59,7 @@ struct RenderParams {
   uint32_t* slabBusy;      // [wave][kSlabsPerWave] 1 while a handed-over slab waits for its folder
   unsigned long long* schedDiag;  // kSchedDiagWords counters, accumulated over launches (dmt_sched_diag)
   int maxDepth;
+  int shadeThreshold;         // BVH megakernel: shade when this many lanes of the wave have finished their rays (bvhShadeThreshold)
   EnvView env;                // A18 env map (w == 0: none); read by the *_env kernels only
   // SURVEY 8f-3 emissive triangles; read by the *_area kernels only
   uint32_t const* areaOf;     // [triCount] index into areaTri / areaLe, 0xFFFFFFFF = not emissive
@@ -1336,6 +1337,7 @@ DMT_DEV void megakernel_body_bvh() {
       //    that were still descending: 11 % lane utilisation in node steps).  The loop ends when enough lanes
       //    wait for shading.
       BvhView const bvh = load_bvh(Pk);
+      int const shadeThreshold = kargs(Pk)->shadeThreshold > 1 ? kargs(Pk)->shadeThreshold : 1;  // (0 would never let the wave traverse)
       for (;;) {
         bool traversing = tv.phase == TR_CLOSEST || tv.phase == TR_SHADOW;
         if (traversing && tv.cur == kBvhEmpty) {  // ray finished: next ray of the round, or done
@@ -1352,7 +1354,7 @@ DMT_DEV void megakernel_body_bvh() {
         bool const onLeaf = traversing && (tv.cur & kBvhLeafFlag) != 0u;  // cur != kBvhEmpty here
         int const nNode = __popcll(__ballot(onNode)), nLeaf = __popcll(__ballot(onLeaf));
         if (nNode + nLeaf == 0) break;
-        if (__popcll(__ballot(tv.phase == TR_DONE)) >= DMT_BVH_SHADE_THRESHOLD) break;
+        if (__popcll(__ballot(tv.phase == TR_DONE)) >= shadeThreshold) break;
         // (parking a found leaf and carrying on with node steps, Aila & Laine's speculative traversal, was measured here in
         //  round 2 and removed: 8 % fewer wave iterations but 5 % slower, the extra dependent LDS pop lengthens every node step)
 #ifdef DMT_BVH_BOTH_STEPS  // experiment: every traversing lane advances every iteration (node and leaf code both run)
@@ -1687,6 +1689,7 @@ struct dmt_ctx {
   std::vector<float> h_xs, h_ys, h_zs;  // host copy of the soup (the builder's input)
   std::vector<uint32_t> h_mat;
   Bvh4Node* d_bvhNodes = nullptr;
+  int shadeThresholdEnv = 0;  // DMT_BVH_SHADE_THRESHOLD from the environment, 0 = choose by tree size
   TriPair* d_trisBvh = nullptr;   // leaf storage of the BVH
   uint32_t* d_overflow = nullptr;
   size_t overflowThreads = 0;
@@ -1883,6 +1886,22 @@ BvhView bvhView(dmt_ctx const* c, size_t threads) {
   return b;
 }
 
+// BVH megakernel: how many lanes of a wave must have finished their rays before the wave stops traversing and shades
+// (megakernel_body_bvh, step C).  Traversing lanes idle while the wave shades and finished lanes idle while it traverses, so
+// the best value follows the cost ratio of the two -- low where rays take hundreds of steps, high where the tree is shallow
+// and shading dominates.  Measured on MI355X, Msamples/s by threshold (profiles/r03/shade_threshold_sweep.txt):
+//   Cornell box, 6 nodes, depth 3             32: 1 923   48: 2 184   56: 2 266   60: 2 244   64: 2 053
+//   sphere.fbx + veranda, 123 nodes, depth 5  32: 6 867   48: 7 416   56: 7 683   64: 7 800
+//   tessellated sphere, 4 588 nodes, depth 10 32: 3 043   48: 3 381   52: 3 399   56: 3 365   64: 2 748
+//   1 M random triangles, 300 k nodes         28: 490     32: 489     36: 485     40: 473     48: 452
+//   16 M random triangles                     24: 435     28: 439     32: 437     36: 436
+// The step between 16 k and 128 k nodes is interpolated, not measured.  DMT_BVH_SHADE_THRESHOLD in the environment overrides
+// the choice (tuning runs).  Results do not depend on it.
+int bvhShadeThreshold(dmt_ctx const* c) {
+  if (c->shadeThresholdEnv > 0) return c->shadeThresholdEnv;
+  uint32_t const n = c->bvhNodeCount;
+  return n <= 1024u ? 56 : n <= 16384u ? 52 : n <= 131072u ? 40 : DMT_BVH_SHADE_THRESHOLD;
+}
 // scene / camera / limits part of the argument struct (what the path-tracing device code reads)
 RenderParams baseParams(dmt_ctx const* c, size_t threads) {
   RenderParams P{};
@@ -1891,6 +1910,7 @@ RenderParams baseParams(dmt_ctx const* c, size_t threads) {
   P.cam = c->xf;
   P.sp = c->sp;
   P.maxDepth = c->maxDepth;
+  P.shadeThreshold = bvhShadeThreshold(c);
   P.env = c->env;
   P.areaOf = c->d_areaOf, P.areaTri = c->d_areaTri, P.areaLe = c->d_areaLe, P.areaCount = c->areaCount;
   if (c->texCount > 0) P.texRgba = c->d_texRgba, P.texDesc = c->d_texDesc, P.matTex = c->d_matTex, P.triUv = c->d_triUv;
@@ -2137,6 +2157,10 @@ int dmt_ctx_create(int device_ordinal, dmt_ctx** out) {
   if (char const* e3 = std::getenv("DMT_BVH_STRATEGY")) {  // experiments: 0 auto, 1 megakernel, 2 wavefront
     int const v = std::atoi(e3);
     ctx->bvhStrategy = v < 0 || v > 2 ? 0 : v;
+  }
+  if (char const* e5 = std::getenv("DMT_BVH_SHADE_THRESHOLD")) {  // tuning runs (bvhShadeThreshold)
+    int const v = std::atoi(e5);
+    ctx->shadeThresholdEnv = v < 1 ? 0 : (v > 64 ? 64 : v);
   }
   if (char const* e4 = std::getenv("DMT_WF_PATHS")) {
     long long const v = std::atoll(e4);
@@ -2601,6 +2625,7 @@ static int renderImpl(dmt_ctx* ctx, uint32_t sample_offset, uint32_t spp, int x0
   P.numItems = tiles > uint32_t(ctx->rank) ? (tiles - uint32_t(ctx->rank) + uint32_t(ctx->world) - 1) / uint32_t(ctx->world) : 0;
   P.sampleOffset = sample_offset, P.spp = spp;
   P.maxDepth = ctx->maxDepth;
+  P.shadeThreshold = bvhShadeThreshold(ctx);
   if (P.numItems == 0) return DMT_OK;
   uint32_t const ownedTiles = P.numItems;
   // BVH launches run as the megakernel unless the wavefront form (wavefront.hpp) is asked for: on the measured scenes
