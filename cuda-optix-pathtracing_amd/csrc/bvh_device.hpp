@@ -166,15 +166,23 @@ DMT_DEV void kswap(uint32_t& a, uint32_t& b) {
   uint32_t const lo = a < b ? a : b, hi = a < b ? b : a;  // v_min_u32 / v_max_u32
   a = lo, b = hi;
 }
-// node step: cur is an inner node
+// the 48 bytes of a node that a step reads
+struct NodeWords {
+  uint4 w0;  // ox oy oz meta
+  uint4 w1;  // childBase leafBase qlox qhix
+  uint4 w2;  // qloy qhiy qloz qhiz
+};
+DMT_DEV NodeWords node_fetch(BvhView const& bv, uint32_t ref) {
+  uint4 const* const nb = reinterpret_cast<uint4 const*>(bv.nodes + ref);
+  return {nb[0], nb[1], nb[2]};
+}
+// node step: cur is an inner node whose words are `nd` (fetched by the caller: the megakernel issues the loads of a lane's
+// NEXT node at the end of the step that found it, see megakernel_body_bvh)
 template <bool STATS = false>
-DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
+DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, NodeWords const& nd, TraversalCounters* tc = nullptr) {
   float const tlimit = tv.tlim;
-  uint4 const* const nb = reinterpret_cast<uint4 const*>(bv.nodes + tv.cur);
   if constexpr (STATS) ++tc->nodes;
-  uint4 const w0 = nb[0];  // ox oy oz meta
-  uint4 const w1 = nb[1];  // childBase leafBase qlox qhix
-  uint4 const w2 = nb[2];  // qloy qhiy qloz qhiz
+  uint4 const w0 = nd.w0, w1 = nd.w1, w2 = nd.w2;
   uint32_t const meta = w0.w;
   f3 const scale = mk3(__uint_as_float((meta << 23) & 0x7F800000u), __uint_as_float((meta << 15) & 0x7F800000u),
                        __uint_as_float((meta << 7) & 0x7F800000u));
@@ -225,6 +233,10 @@ DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc =
     if (p1) tv.stack.push(bv, r1);
     tv.cur = p0 ? r0 : tv.stack.pop(bv);
   }
+}
+template <bool STATS = false>
+DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, TraversalCounters* tc = nullptr) {
+  trav_node<STATS>(bv, tv, node_fetch(bv, tv.cur), tc);
 }
 // leaf test: `ref` is a leaf reference (one triangle pair) of the ray (o, d); updates the best hit / the occlusion flag only
 template <bool STATS = false>
