@@ -1342,8 +1342,7 @@ DMT_DEV void megakernel_body_bvh() {
       // issued right there, and the step selection, the other kind of step for the other lanes and the loop overhead run
       // under their latency (1 M triangles: 488 -> 517 Msamples/s, 16 M: 440 -> 466).  Fetched anew here for every lane on a
       // node, so that nothing of it is live while the wave shades.  Measured and lost: a leaf's pair words ahead as well (430 in
-      // shared registers, 384 in registers of their own) and the hit nearest child ahead of the stack round trip (449) -- each
-      // puts MORE vector-memory instructions into every step, and those cost the CU's address path the same for one lane as for 64.
+      // shared registers, 384 in registers of their own) and the hit nearest child ahead of the stack round trip (449); DESIGN 4.2.5.
       NodeWords nd{};
       if ((tv.phase == TR_CLOSEST || tv.phase == TR_SHADOW) && !(tv.cur & kBvhLeafFlag)) nd = node_fetch(bvh, tv.cur);
       for (;;) {
