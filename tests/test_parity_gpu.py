@@ -639,6 +639,38 @@ def test_bvh_overflow_stack_variant(renderer):
     assert (root / "cuda-optix-pathtracing_amd" / "csrc" / "libdmt_hip.so").exists()
 
 
+def test_bvh_shade_threshold_is_scheduling_only(pkg, monkeypatch):
+    """The BVH megakernel shades when `shadeThreshold` lanes of a wave have finished their rays; the library picks the
+    value by tree size (bvhShadeThreshold) and DMT_BVH_SHADE_THRESHOLD overrides it.  Scheduling only: films must not
+    change by a bit between 1 (shade at once), the defaults and 64 (shade only when every lane waits), and must
+    equal brute force."""
+    scene = pkg.host_scene.random_triangle_scene(30000, width=96, height=64)
+    films = []
+    for thr in (None, "1", "17", "64"):
+        if thr is None:
+            monkeypatch.delenv("DMT_BVH_SHADE_THRESHOLD", raising=False)
+        else:
+            monkeypatch.setenv("DMT_BVH_SHADE_THRESHOLD", thr)
+        with pkg.Renderer(0) as r:
+            r.upload_scene(scene)
+            r.set_limits(8)
+            r.set_accel(1)
+            r.render(24)
+            r.sync()
+            films.append(r.download_film())
+    monkeypatch.delenv("DMT_BVH_SHADE_THRESHOLD", raising=False)
+    with pkg.Renderer(0) as r:
+        r.upload_scene(scene)
+        r.set_limits(8)
+        r.set_accel(0)
+        r.render(24)
+        r.sync()
+        brute = r.download_film()
+    assert brute[0][..., :3].max() > 0 and brute[1][..., 3].max() == 24
+    for f in films:
+        assert np.array_equal(brute[0], f[0]) and np.array_equal(brute[1], f[1])
+
+
 def test_row_band_scheduling_is_bit_exact(pkg, O, monkeypatch):
     """A GPU that owns fewer tiles than it has resident waves schedules row bands of its tiles (2 or 4 items per
     8x8 tile).  Scheduling only: the film must not change by a bit, partial tiles and partitions included."""
