@@ -191,9 +191,11 @@ def build_roofline(workload, stats, avg_ms, samples_per_launch, kspp, pmc, info=
                       "valu_insts_x4_per_simd_cycle": round(insts, 4) if insts is not None else None,
                       "formula": "SQ_ACTIVE_INST_VALU x 4 (the counter is in quad-cycles) / (1024 SIMDs x SQ_BUSY_CYCLES / 32) of the same PMC pass",
                       "raw_above_one": "the counter adds up, per wave, the quad-cycles during which that wave has a VALU instruction in flight; on a "
-                                       "saturated SIMD the issue of one wave's instruction overlaps the last stage of another wave's, so the sum "
-                                       "exceeds the SIMD's own cycles by a few per cent (1.04 on the Cornell kernel, whose instruction count x 4 "
-                                       "cycles is 1.00 of the SIMD cycles).  valu_busy clips at 1; below saturation raw is an upper bound",
+                                       "saturated SIMD the issue of one wave's instruction overlaps the last stage of another wave's, and a "
+                                       "simple wave64 instruction holds the pipe for ~2.5 cycles, not 4 (tools/ubench), so neither this sum nor "
+                                       "the instruction count x 4 is an exact cycle count: the Cornell kernel reads 1.10 and 1.07 of the SIMD "
+                                       "cycles (1.04 and 1.00 while its polynomial code was packed, 4.5-cycle instructions).  valu_busy clips "
+                                       "at 1; below saturation raw is an upper bound",
                       "lane_utilisation": pmc.get("lane_utilisation"), "wait_any_share": pmc.get("wait_any_share"),
                       "valu_insts_per_sample": pmc.get("valu_insts_per_sample")}
     out = {"kernel": kernel_name(scene_kind), "avg_launch_ms": round(avg_ms, 4), "traffic": traffic,
