@@ -258,6 +258,27 @@ def build_scene(pkg, scene_kind, width, height):
     return hs.random_triangle_scene(count, width=width, height=height, extent=extent)
 
 
+def oracle_band(O, width, height, spp, max_depth, want_rows, threads, film_mean):
+    """Rows of the Cornell frame, spread evenly, rendered by the CPU oracle (the checker, never the thing measured here):
+    returns the parity record of the GPU film on those rows and the oracle's work counters."""
+    import numpy as np
+    oscene = O.cornell_box(width, height)
+    nrows = max(1, min(want_rows, height, int(2e7 // (width * spp)) or 1))
+    rows = sorted({int((i + 0.5) * height / nrows) for i in range(nrows)})
+    stats = {}
+    omean = np.zeros((height, width, 4), np.float32)
+    om2 = np.zeros((height, width, 4), np.float32)
+    for y in rows:
+        _, _, st = O.render(oscene, spp, max_depth=max_depth, region=(0, y, width, y + 1), threads=threads,
+                            film=(omean, om2), want_stats=True)
+        for k, v in st.items():
+            stats[k] = stats.get(k, 0) + v
+    d = film_mean[rows, :, :3].astype(np.float64) - omean[rows, :, :3]
+    parity = {"rmse_vs_cpu_rows": float(np.sqrt((d ** 2).mean(axis=2)).mean()), "tolerance": 1e-3,
+              "rows": len(rows), "samples": int(stats["samples"])}
+    return parity, stats
+
+
 SECONDARY_WORKLOAD = "random1M_1024x1024_512spp_8bounces"
 
 
@@ -315,6 +336,9 @@ def main():
                     help="experiment (VERDICT r2 item 9): run a Cornell workload through the BVH kernel instead of the brute-force loop "
                          "(films are bit-identical); the roofline record then still describes the brute-force model")
     ap.add_argument("--cpu-band-rows", type=int, default=16)
+    ap.add_argument("--parity-rows", type=int, default=0,
+                    help="Cornell workloads without the cpu_baseline leg (N > 1, --no-cpu-baseline): check this many rows of the combined film "
+                         "against the CPU oracle on rank 0 (untimed)")
     args = ap.parse_args()
 
     import numpy as np
@@ -489,20 +513,12 @@ def main():
                           f"(oracle/dmt_oracle.cpp, g++ -O2 -ffp-contract=off), 32x32-tile std::thread pool",
             }
             # (2) untimed: rows of THIS workload's frame -> work counters for the models + a parity band for the GPU film
-            oscene = O.cornell_box(width, height)
-            nrows = max(1, min(args.cpu_band_rows, height, int(2e7 // (width * spp)) or 1))
-            rows = sorted({int((i + 0.5) * height / nrows) for i in range(nrows)})
-            stats = {}
-            omean = np.zeros((height, width, 4), np.float32)
-            om2 = np.zeros((height, width, 4), np.float32)
-            for y in rows:
-                _, _, st = O.render(oscene, spp, max_depth=max_depth, region=(0, y, width, y + 1), threads=threads,
-                                    film=(omean, om2), want_stats=True)
-                for k, v in st.items():
-                    stats[k] = stats.get(k, 0) + v
-            d = film_mean[rows, :, :3].astype(np.float64) - omean[rows, :, :3]
-            parity = {"rmse_vs_cpu_rows": float(np.sqrt((d ** 2).mean(axis=2)).mean()), "tolerance": 1e-3,
-                      "rows": len(rows), "samples": int(stats["samples"])}
+            parity, stats = oracle_band(O, width, height, spp, max_depth, args.cpu_band_rows, threads, film_mean)
+        elif args.parity_rows > 0:
+            # no cpu_baseline leg (N > 1 or --no-cpu-baseline), but the combined film is still checked against the CPU oracle on a few rows
+            O = graft.load_oracle()
+            threads = int(os.environ.get("DMT_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+            parity, stats = oracle_band(O, width, height, spp, max_depth, args.parity_rows, threads, film_mean)
         if stats is None:
             stats = WORKLOAD_STATS.get(args.workload)
         roofline = None
