@@ -43,10 +43,17 @@ struct BvhStack {
     ++sp;
   }
   DMT_DEV uint32_t pop(BvhView const& bv) {
+    // Whole wave within the LDS part (the usual case): a plain ds_read.  The general form below reads LDS or the overflow
+    // column per lane, and hipcc turns its two loads into ONE flat_load through a selected generic pointer, however it is
+    // written -- an LDS access by way of the vector-memory path, waited for with vmcnt(0) AND lgkmcnt(0).  The wave-uniform
+    // branch keeps that out of the common path.
+    if (!__any(sp > kBvhLdsStack)) {
+      if (sp == 0) return kBvhEmpty;
+      --sp;
+      return s_bvh_stack[sp * kLdsThreads + int(threadIdx.x)];
+    }
     if (sp == 0) return kBvhEmpty;
     --sp;
-    // LDS read unconditional (clamped slot), global read only when needed: selecting between the two
-    // POINTERS would make hipcc emit one flat_load through a generic pointer
     int const slot = sp < kBvhLdsStack ? sp : kBvhLdsStack - 1;
     uint32_t v = s_bvh_stack[slot * kLdsThreads + int(threadIdx.x)];
     if (sp >= kBvhLdsStack) v = column(bv)[size_t(sp - kBvhLdsStack) * bv.overflowStride];
