@@ -14,7 +14,7 @@
 // occupancy; round 1's kernel ran at 75 % of the first two rates.  So:
 //   * Bvh4Node = 48 bytes of payload in a 64-byte slot (one sector, three loads): the children's boxes are
 //     quantised to 8 bits per plane relative to the node's own box (origin + power-of-two scale per axis) and child
-//     references are implicit (inner children contiguous from childBase, leaves contiguous from leafBase).
+//     references are implicit (inner children contiguous from childBase, leaves contiguous from the pair leafRef names).
 //   * TriPair = 80 bytes (five loads): two triangles interleaved component by component for packed math.
 //
 // Correctness contract (tests/test_parity_gpu.py::test_bvh_*): traversal returns exactly the brute-force closest hit
@@ -58,12 +58,13 @@ static_assert(sizeof(TriPair) == 80, "pair size");
 
 // Inner node.  Child k (k < count) has the box  [origin + qlo_k * scale, origin + qhi_k * scale]  per axis, with
 // scale_axis = 2^(exp_axis - 127) and the q's the k-th BYTES of the six plane words.  Children 0 .. inner-1 are the inner
-// nodes childBase + k; children inner .. count-1 are the leaves (triangle pairs) leafBase + (k - inner).
+// nodes childBase + k; children inner .. count-1 are the leaves (triangle pairs) with the REFERENCES leafRef + k, where
+// leafRef = first pair - inner + kBvhLeafFlag (modulo 2^32): a slot's reference is one add from either base (bvh_device.hpp).
 struct Bvh4Node {  // 64-byte slot, 48 bytes read (three 16-byte loads)
   float ox, oy, oz;       // quantisation origin = lower corner of the node's box
   uint32_t meta;          // byte 0-2: biased power-of-two exponent of the x / y / z scale; byte 3: inner | count << 4
   uint32_t childBase;     // first inner child
-  uint32_t leafBase;      // first leaf child (pair index)
+  uint32_t leafRef;       // flagged reference of leaf slot k, minus k:  first pair - inner + kBvhLeafFlag  (mod 2^32)
   uint32_t qlox, qhix;    // byte k: child k's quantised planes
   uint32_t qloy, qhiy, qloz, qhiz;
   uint32_t pad[4];
@@ -366,7 +367,7 @@ inline Result build(float const* xs, float const* ys, float const* zs, uint32_t 
     encodeNode(nd, kb, W.nk, W.nInner);
     nd.childBase = nextChild;
     nextChild += uint32_t(W.nInner);
-    nd.leafBase = uint32_t(out.pairTris.size() / 2);
+    nd.leafRef = uint32_t(out.pairTris.size() / 2) - uint32_t(W.nInner) + kBvhLeafFlag;
     for (int k = W.nInner; k < W.nk; ++k) {
       Node2 const& c = b.nodes[size_t(W.kids[k])];
       uint32_t const t0 = b.order[c.first], t1 = b.order[c.first + (c.count > 1 ? 1 : 0)];

@@ -176,7 +176,7 @@ DMT_DEV void kswap(uint32_t& a, uint32_t& b) {
 // the 48 bytes of a node that a step reads
 struct NodeWords {
   uint4 w0;  // ox oy oz meta
-  uint4 w1;  // childBase leafBase qlox qhix
+  uint4 w1;  // childBase leafRef qlox qhix
   uint4 w2;  // qloy qhiy qloz qhiz
 };
 DMT_DEV NodeWords node_fetch(BvhView const& bv, uint32_t ref) {
@@ -212,12 +212,12 @@ DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, NodeWords const& nd, Tr
   kswap(k0, k2);
   kswap(k1, k3);
   kswap(k1, k2);
-  // implicit references: slot s < inner is node childBase + s, else leaf leafBase + (s - inner)
+  // implicit references: slot s < inner is node childBase + s, else the flagged leaf reference leafRef + s (the builder stores
+  // first pair - inner + kBvhLeafFlag; modulo 2^32 the sum is exact for every leaf slot)
   uint32_t const inner = (meta >> 24) & 0xFu;
-  uint32_t const lb = w1.y - inner;  // may wrap below zero; + slot (>= inner) is exact again modulo 2^32
   auto ref_of = [&](uint32_t key) {
     uint32_t const slot = key & 3u;
-    return slot < inner ? w1.x + slot : ((lb + slot) | kBvhLeafFlag);
+    return (slot < inner ? w1.x : w1.y) + slot;
   };
   uint32_t const r0 = ref_of(k0), r1 = ref_of(k1), r2 = ref_of(k2), r3 = ref_of(k3);
   bool const p3 = k3 < kMissKey, p2 = k2 < kMissKey, p1 = k1 < kMissKey, p0 = k0 < kMissKey;

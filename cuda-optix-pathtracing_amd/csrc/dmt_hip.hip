@@ -1987,7 +1987,7 @@ int buildBvh(dmt_ctx* ctx) {
   // + 3 guard pairs (copies of the last one).  An EMPTY child slot holds an inverted quantised box and no reference of its
   // own; its slab test misses by itself except in one corner: a ray exactly parallel to an axis through a node that is flat
   // on the remaining axes (255 quantisation steps below half an ulp of the plane distance), where near == far.  The slot's
-  // implicit reference is then leafBase + slot - inner, i.e. a pair of the NEXT node -- or, for the last node, up to three
+  // implicit reference is then leafRef + slot, i.e. a pair of the NEXT node -- or, for the last node, up to three
   // pairs past the array.  Testing some real triangle of the scene once more changes no result (the triangle test decides
   // hits, and a scene triangle is a scene triangle); reading past the array would, hence the guards.
   std::vector<TriPair> pairs(npairs ? npairs + 3 : 0);
@@ -2810,7 +2810,7 @@ int dmt_bvh_validate(const float* xs, const float* ys, const float* zs, size_t c
         stack.push_back(c);
         continue;
       }
-      size_t const pair = size_t(n.leafBase) + size_t(k - inner);
+      size_t const pair = size_t(uint32_t(n.leafRef + uint32_t(k) - kBvhLeafFlag));  // the slot's reference without its flag
       if (pair >= npairs) { ok = false; break; }
       uint32_t const t0 = r.pairTris[2 * pair], t1 = r.pairTris[2 * pair + 1];
       maxLeaf = std::max(maxLeaf, t0 == t1 ? 1 : 2);
