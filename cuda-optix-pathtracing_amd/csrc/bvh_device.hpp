@@ -115,14 +115,13 @@ struct TraversalCounters {  // per-lane work counters (stats build of the kernel
 // subtracting first ((origin - o) * inv) would cost three.  A zero direction component gives inf * 0 or inf - inf = NaN on
 // that axis, which max/min drop, i.e. the axis is ignored.  Hits are decided by the triangle test alone.
 struct SlabRay2 {
-  f3 inv, oi;
-  bool negx, negy, negz;
+  f3 inv, oi;  // (which of a node's plane words is the near one is read off inv's sign in the step: as loop-carried flags
+               //  the three cost six SGPRs and eighteen scalar instructions per loop iteration)
 };
 DMT_DEV SlabRay2 slab_ray2(f3 o, f3 d) {
   SlabRay2 r;
   r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   r.oi = mk3(-o.x * r.inv.x, -o.y * r.inv.y, -o.z * r.inv.z);
-  r.negx = d.x < 0.f, r.negy = d.y < 0.f, r.negz = d.z < 0.f;
   return r;
 }
 enum : int { TR_IDLE = 0, TR_CLOSEST = 1, TR_SHADOW = 2, TR_DONE = 3 };
@@ -196,9 +195,11 @@ DMT_DEV void trav_node(BvhView const& bv, Traversal& tv, NodeWords const& nd, Tr
   f3 const a = mk3(scale.x * tv.sr.inv.x, scale.y * tv.sr.inv.y, scale.z * tv.sr.inv.z);
   f3 const b = mk3(fma_(__uint_as_float(w0.x), tv.sr.inv.x, tv.sr.oi.x), fma_(__uint_as_float(w0.y), tv.sr.inv.y, tv.sr.oi.y),
                    fma_(__uint_as_float(w0.z), tv.sr.inv.z, tv.sr.oi.z));
-  uint32_t const nqx = tv.sr.negx ? w1.w : w1.z, fqx = tv.sr.negx ? w1.z : w1.w;
-  uint32_t const nqy = tv.sr.negy ? w2.y : w2.x, fqy = tv.sr.negy ? w2.x : w2.y;
-  uint32_t const nqz = tv.sr.negz ? w2.w : w2.z, fqz = tv.sr.negz ? w2.z : w2.w;
+  // 1/d < 0 exactly when d < 0, except d = -0 (1/d = -inf): that axis is dropped as NaN whichever word is called near
+  bool const negx = tv.sr.inv.x < 0.f, negy = tv.sr.inv.y < 0.f, negz = tv.sr.inv.z < 0.f;
+  uint32_t const nqx = negx ? w1.w : w1.z, fqx = negx ? w1.z : w1.w;
+  uint32_t const nqy = negy ? w2.y : w2.x, fqy = negy ? w2.x : w2.y;
+  uint32_t const nqz = negz ? w2.w : w2.z, fqz = negz ? w2.z : w2.w;
   // An empty slot holds the inverted box (lo 255, hi 0): on every axis with a finite slope its near plane lies a whole
   // 255 * |a| behind its far plane, so it misses by itself -- unless 255 * |a| vanishes against |b| in fp32 on every axis
   // that has a finite slope (axis-parallel ray, node flat on the other axes).  Then the slot "hits" and its implicit
