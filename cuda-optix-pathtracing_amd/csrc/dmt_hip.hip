@@ -1313,16 +1313,16 @@ DMT_DEV void megakernel_body_bvh() {
       //    .x half (the traversal keeps no copy of it): a round with a shadow ray swaps the halves, and swaps them back when
       //    the shadow ray is done, so that the closest-hit ray is in .x again when the lane shades.
       if (idle && (st.active || st.hasShadow)) {
-        tv.doC = st.active, tv.doS = st.hasShadow;
+        // (what the round consists of is st.active / st.hasShadow themselves: nothing changes them before the lane shades)
         tv.bestTri = -1, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false;
-        if (tv.doS) {
+        if (st.hasShadow) {
           tv.phase = TR_SHADOW;
           swap_rays(st);
         } else {
           tv.phase = TR_CLOSEST;
         }
-        trav_set_ray(tv, ray_org(st), ray_dir(st), tv.doS ? st.smax : kInf);
-        if constexpr (STATS) ls.closest += tv.doC ? 1u : 0u, ls.shadow += tv.doS ? 1u : 0u;
+        trav_set_ray(tv, ray_org(st), ray_dir(st), st.hasShadow ? st.smax : kInf);
+        if constexpr (STATS) ls.closest += st.active ? 1u : 0u, ls.shadow += st.hasShadow ? 1u : 0u;
       }
       // R. item cur has no units left: is it complete?
       if (W.alloc != W.cur || W.nextUnit == W.totalUnits) {
@@ -1349,7 +1349,7 @@ DMT_DEV void megakernel_body_bvh() {
         bool traversing = tv.phase == TR_CLOSEST || tv.phase == TR_SHADOW;
         if (traversing && tv.cur == kBvhEmpty) {  // ray finished: next ray of the round, or done
           if (tv.phase == TR_SHADOW) swap_rays(st);  // .x = the closest-hit ray again
-          if (tv.phase == TR_SHADOW && tv.doC) {
+          if (tv.phase == TR_SHADOW && st.active) {
             tv.phase = TR_CLOSEST;
             trav_set_ray(tv, ray_org(st), ray_dir(st), kInf);
             nd = node_fetch(bvh, tv.cur);  // the root
@@ -1388,8 +1388,8 @@ DMT_DEV void megakernel_body_bvh() {
       // D. resolve + shade every lane that has finished its round
       if constexpr (STATS) ++ls.itShade, ls.lanesShade += tv.phase == TR_DONE ? 1u : 0u;
       if (tv.phase == TR_DONE) {
-        if constexpr (STATS) ls.bounces += (tv.doC && tv.bestTri >= 0 && st.depth < kargs(Pk)->maxDepth) ? 1u : 0u;
-        lane_finish<ENV, AREA, TEX, LTREE, true>(Pk, st, tv.doC, tv.doS, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
+        if constexpr (STATS) ls.bounces += (st.active && tv.bestTri >= 0 && st.depth < kargs(Pk)->maxDepth) ? 1u : 0u;
+        lane_finish<ENV, AREA, TEX, LTREE, true>(Pk, st, st.active, st.hasShadow, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
         tv.phase = TR_IDLE;
       }
     }
