@@ -133,10 +133,11 @@ struct Traversal {
   uint32_t cur;
   BvhStack stack;
   SlabRay2 sr;       // slab form of the ray of the current phase
-  float tlim;        // closest: t of the best hit so far (kInf: none); shadow: the light's distance
+  float tlim;        // closest: t of the best hit so far (kInf: none); shadow: the light's distance, NEGATIVE once the ray is occluded
+                     // (no separate flag: a bool changed inside the traversal loop is a lane mask with scalar bookkeeping at every join)
   int bestTri;       // closest: ORIGINAL index of the best hit, -1 = none
   float bu, bv;
-  bool occluded;
+  DMT_DEV bool occluded() const { return tlim < 0.f; }  // of the shadow ray just traversed
 };
 DMT_DEV void trav_set_ray(Traversal& tv, f3 o, f3 d, float tlim) {
   tv.sr = slab_ray2(o, d);
@@ -257,14 +258,14 @@ DMT_DEV void trav_leaf_ref(BvhView const& bv, Traversal& tv, f3 o, f3 d, uint32_
     if (h.valid1 && (h.t.y < tv.tlim || (h.t.y == tv.tlim && h.orig1 < uint32_t(tv.bestTri))))
       tv.tlim = h.t.y, tv.bu = h.u.y, tv.bv = h.v.y, tv.bestTri = int(h.orig1);
   } else if ((h.valid0 && h.t.x < tv.tlim) || (h.valid1 && h.t.y < tv.tlim)) {
-    tv.occluded = true;
+    tv.tlim = -1.f;
   }
 }
 // leaf step of the synchronous traversal: cur is a leaf reference
 template <bool STATS = false>
 DMT_DEV void trav_leaf(BvhView const& bv, Traversal& tv, f3 o, f3 d, TraversalCounters* tc = nullptr) {
   trav_leaf_ref<STATS>(bv, tv, o, d, tv.cur, tc);
-  tv.cur = (tv.phase != TR_CLOSEST && tv.occluded) ? kBvhEmpty : tv.stack.pop(bv);
+  tv.cur = tv.tlim < 0.f ? kBvhEmpty : tv.stack.pop(bv);  // (a closest-hit limit is never negative)
 }
 // ---- whole traversals of one ray per lane (test kernels, lane_step<BVH>): the same step functions in a loop ----
 template <bool STATS>
@@ -284,7 +285,7 @@ DMT_DEV void bvh_closest(BvhView const& bv, bool active, f3 o, f3 d, uint32_t gt
   Traversal tv{};
   if constexpr (STATS) tv.stack.ovfCount = &tc->overflowPushes;
   tv.phase = TR_CLOSEST;
-  tv.bestTri = -1, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false;
+  tv.bestTri = -1, tv.bu = 0.f, tv.bv = 0.f;
   trav_set_ray(tv, o, d, kInf);
   if (!active) tv.cur = kBvhEmpty;
   trav_run<STATS>(bv, tv, o, d, tc);
@@ -297,11 +298,11 @@ DMT_DEV bool bvh_any(BvhView const& bv, bool active, f3 o, f3 d, float tmax, uin
   Traversal tv{};
   if constexpr (STATS) tv.stack.ovfCount = &tc->overflowPushes;
   tv.phase = TR_SHADOW;
-  tv.bestTri = -1, tv.occluded = false;
+  tv.bestTri = -1;
   trav_set_ray(tv, o, d, tmax);
   if (!active) tv.cur = kBvhEmpty;
   trav_run<STATS>(bv, tv, o, d, tc);
-  return tv.occluded;
+  return tv.occluded();
 }
 
 }  // namespace dmt

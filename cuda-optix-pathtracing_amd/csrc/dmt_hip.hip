@@ -1314,7 +1314,7 @@ DMT_DEV void megakernel_body_bvh() {
       //    the shadow ray is done, so that the closest-hit ray is in .x again when the lane shades.
       if (idle && (st.active || st.hasShadow)) {
         // (what the round consists of is st.active / st.hasShadow themselves: nothing changes them before the lane shades)
-        tv.bestTri = -1, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false;
+        tv.bestTri = -1, tv.bu = 0.f, tv.bv = 0.f;
         if (st.hasShadow) {
           tv.phase = TR_SHADOW;
           swap_rays(st);
@@ -1348,7 +1348,10 @@ DMT_DEV void megakernel_body_bvh() {
       for (;;) {
         bool traversing = tv.phase == TR_CLOSEST || tv.phase == TR_SHADOW;
         if (traversing && tv.cur == kBvhEmpty) {  // ray finished: next ray of the round, or done
-          if (tv.phase == TR_SHADOW) swap_rays(st);  // .x = the closest-hit ray again
+          if (tv.phase == TR_SHADOW) {
+            swap_rays(st);         // .x = the closest-hit ray again
+            st.smax = tv.tlim;     // the shadow ray's verdict (negative = occluded) outlives the closest-hit traversal here
+          }
           if (tv.phase == TR_SHADOW && st.active) {
             tv.phase = TR_CLOSEST;
             trav_set_ray(tv, ray_org(st), ray_dir(st), kInf);
@@ -1389,7 +1392,7 @@ DMT_DEV void megakernel_body_bvh() {
       if constexpr (STATS) ++ls.itShade, ls.lanesShade += tv.phase == TR_DONE ? 1u : 0u;
       if (tv.phase == TR_DONE) {
         if constexpr (STATS) ls.bounces += (st.active && tv.bestTri >= 0 && st.depth < kargs(Pk)->maxDepth) ? 1u : 0u;
-        lane_finish<ENV, AREA, TEX, LTREE, true>(Pk, st, st.active, st.hasShadow, tv.bestTri, tv.bu, tv.bv, tv.occluded, sink);
+        lane_finish<ENV, AREA, TEX, LTREE, true>(Pk, st, st.active, st.hasShadow, tv.bestTri, tv.bu, tv.bv, st.smax < 0.f, sink);
         tv.phase = TR_IDLE;
       }
     }

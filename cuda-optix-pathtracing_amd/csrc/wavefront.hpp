@@ -168,7 +168,7 @@ DMT_DEV void wf_trace_body(WfParams const& W) {
           if (tv.doS) start_shadow();
           else tv.phase = TR_IDLE;
         } else {
-          reinterpret_cast<uint32_t*>(wf_plane(W, WF_OCCLUDED))[path] = tv.occluded ? 1u : 0u;
+          reinterpret_cast<uint32_t*>(wf_plane(W, WF_OCCLUDED))[path] = tv.occluded() ? 1u : 0u;
           tv.phase = TR_IDLE;
         }
       }
@@ -191,7 +191,7 @@ DMT_DEV void wf_trace_body(WfParams const& W) {
           path = queue[my];
           uint32_t const f = flagsPlane[path];
           tv.doC = (f & kWfActive) != 0u, tv.doS = (f & kWfShadow) != 0u;
-          tv.bestTri = -1, tv.bu = 0.f, tv.bv = 0.f, tv.occluded = false;
+          tv.bestTri = -1, tv.bu = 0.f, tv.bv = 0.f;
           if (tv.doC) {
             tv.phase = TR_CLOSEST;
             ro = mk3(wf_plane(W, WF_OX)[path], wf_plane(W, WF_OY)[path], wf_plane(W, WF_OZ)[path]);
